@@ -1,0 +1,265 @@
+/*
+ * vwgpu.h -- C ABI of the MI355X (gfx950) MODWT / SWT engine.
+ *
+ * Drop-in boundary for the batched MODWT path of Prophetizo/VectorWave.  The
+ * reference has no FFI: its seam is a set of static Java methods that process
+ * one signal with one filter (WaveletOperations.java:25-49).  That is too fine
+ * a grain for a GPU, so the boundary moves up to whole-batch calls; every entry
+ * point below names the reference method(s) it replaces (paths relative to
+ * src/main/java/ai/prophetizo/wavelet/).  A Java 23 host binds these symbols
+ * with java.lang.foreign downcalls over off-heap MemorySegments.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns a vw_status.
+ *   - all data is IEEE-754 binary64; element counts are int64_t.
+ *   - signals:       row-major [B][N]
+ *   - coefficients:  row-major [B][J+1][N], bands ordered d_1, ..., d_J, a_J
+ *                    (level 1 = finest; the single-level transform is J = 1,
+ *                    i.e. [B][2][N] = detail, approximation).
+ *   - filters are the wavelet's UNSCALED taps (what lowPassDecomposition() etc.
+ *     return); the library applies the reference's `tap * (1.0/Math.sqrt(2.0))`
+ *     scaling (modwt/MODWTTransform.java:133-142) itself, in binary64, so host
+ *     and device agree bit for bit.
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc'd or any framework's
+ *     device allocation on the context's GPU) and enqueue on `stream`
+ *     (a hipStream_t passed as void*; NULL = the context's own stream) without
+ *     synchronising.  The others take HOST pointers, stage through device
+ *     buffers owned by the context, and return when the result is in the
+ *     caller's buffer.  The caller owns every buffer it passes; the library
+ *     keeps no pointer after return.
+ *   - arithmetic is the reference's scalar path: products and sums rounded
+ *     separately (no FMA contraction), taps added in ascending order.
+ */
+#ifndef VWGPU_H
+#define VWGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vw_ctx vw_ctx;
+
+/* Status codes.  1..7 and 103/104 carry the number of the reference's ErrorCode
+ * (exception/ErrorCode.java:24-75: VAL_001..VAL_007, CFG_003, CFG_004). */
+typedef enum vw_status {
+    VW_OK = 0,
+    VW_E_NULL = 1,            /* VAL_NULL_ARGUMENT: a required pointer is NULL         */
+    VW_E_NONFINITE = 3,       /* VAL_NON_FINITE_VALUES: NaN/Inf in the input           */
+    VW_E_NOT_POSITIVE = 4,    /* VAL_NOT_POSITIVE: negative threshold / count          */
+    VW_E_TOO_LARGE = 5,       /* VAL_TOO_LARGE: level - 1 >= 31 or size overflow       */
+    VW_E_EMPTY = 6,           /* VAL_EMPTY: N == 0                                      */
+    VW_E_LENGTH_MISMATCH = 7, /* VAL_LENGTH_MISMATCH: filter lengths unusable           */
+    VW_E_BOUNDARY = 103,      /* CFG_UNSUPPORTED_BOUNDARY_MODE                          */
+    VW_E_LEVEL = 104,         /* CFG_INVALID_DECOMPOSITION_LEVEL                        */
+    VW_E_NO_DEVICE = 900,     /* no usable gfx950 device / HIP runtime failure          */
+    VW_E_HIP = 901,           /* a HIP call failed; see vw_last_error                   */
+    VW_E_NOMEM = 902,         /* device or host allocation failed                       */
+    VW_E_WORKSPACE = 903      /* caller-supplied workspace too small                    */
+} vw_status;
+
+/* Boundary modes accepted by the MODWT classes (modwt/MODWTTransform.java:88-90). */
+typedef enum vw_boundary {
+    VW_BOUNDARY_PERIODIC = 0,
+    VW_BOUNDARY_ZERO_PADDING = 1,
+    VW_BOUNDARY_SYMMETRIC = 2
+} vw_boundary;
+
+/* Flags (bitwise OR). */
+enum {
+    /* Scan the input for NaN/Inf while it is loaded and report the first bad
+     * flat index, as ValidationUtils.validateFiniteValues does for forward()/
+     * decompose() (util/ValidationUtils.java:106-117).  Without it the call
+     * behaves like forwardBatchOptimized, which skips validation
+     * (modwt/MODWTTransform.java:537-587). */
+    VW_FLAG_CHECK_FINITE = 1,
+    /* SYMMETRIC single-level inverse only: reflect t+l as inverseBatchOptimized
+     * does (modwt/MODWTTransform.java:644-657) instead of t-l as inverse() does
+     * (:269-287).  The two reference methods disagree; the caller picks. */
+    VW_FLAG_SYMMETRIC_BATCH_VARIANT = 2,
+    /* Skip the reference's level-count check (1 <= J <= vw_max_levels). */
+    VW_FLAG_NO_LEVEL_CHECK = 4,
+    /* The call comes from the single-level class MODWTTransform (requires
+     * levels == 1): any N >= 1 is accepted, filters are never truncated, and the
+     * SYMMETRIC inverse adds each tap's two products as a pair
+     * (modwt/MODWTTransform.java:269-287).  Without it the call follows
+     * MultiLevelMODWTTransform: level-count check, filters longer than the
+     * signal truncated to its length (modwt/MultiLevelMODWTTransform.java:
+     * 801-806, 628-636), SYMMETRIC inverse adding the low-pass and high-pass
+     * products to the sum one after the other (:664-685). */
+    VW_FLAG_SINGLE_LEVEL = 8
+};
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Create a context on HIP device `device` (one context per GPU; the multi-GPU
+ * layout is one process, or one context, per device with rows sharded by the
+ * host).  Fails with VW_E_NO_DEVICE if the device is missing. */
+int32_t vw_init(int32_t device, vw_ctx **out_ctx);
+int32_t vw_destroy(vw_ctx *ctx);
+/* Message of the last failure on this context (never NULL; valid until the next call). */
+const char *vw_last_error(const vw_ctx *ctx);
+/* Human-readable description of the execution back end; the truthful
+ * counterpart of WaveletOperations.getPerformanceInfo (WaveletOperations.java:56-72). */
+const char *vw_performance_info(const vw_ctx *ctx);
+/* Block until everything enqueued on the context's own stream has finished. */
+int32_t vw_synchronize(vw_ctx *ctx);
+/* Number of HIP devices visible to the process (0 if none / no runtime). */
+int32_t vw_device_count(void);
+
+/* ---- pure host helpers ------------------------------------------------- */
+
+/* MultiLevelMODWTTransform.calculateMaxLevels / getMaximumLevels
+ * (modwt/MultiLevelMODWTTransform.java:477-523, :776-778): largest j < 10 with
+ * (L-1)*2^(j-1)+1 <= N; 0 when N <= L. */
+int32_t vw_max_levels(int64_t n, int32_t filter_len);
+
+/* ---- forward ------------------------------------------------------------ */
+
+/* Batched J-level forward MODWT.  Replaces MODWTTransform.forward /
+ * forwardBatch / forwardBatchOptimized for J = 1 (modwt/MODWTTransform.java:
+ * 123-179, 459-487, 537-587) and MultiLevelMODWTTransform.decompose /
+ * decomposeMutable + transformAtLevel + applyScaledMODWT for J >= 1
+ * (modwt/MultiLevelMODWTTransform.java:214-353, 528-538, 793-834), which in turn
+ * replace WaveletOperations.circularConvolveMODWT / zeroPaddingConvolveMODWT /
+ * symmetricConvolveMODWT (WaveletOperations.java:25-49).
+ *   x [B][N] in, coeffs [B][J+1][N] out; h/g = lowPass/highPassDecomposition().
+ *   Enforces 1 <= J <= vw_max_levels(N, lh) like decompose() unless
+ *   VW_FLAG_SINGLE_LEVEL or VW_FLAG_NO_LEVEL_CHECK is given.
+ *   first_bad (may be NULL): with VW_FLAG_CHECK_FINITE receives the flat index
+ *   b*N+t of the first non-finite input, or -1.  The host variant then returns
+ *   VW_E_NONFINITE; the _dev variant writes the int64 through the DEVICE
+ *   pointer first_bad_dev asynchronously and always returns VW_OK. */
+int32_t vw_modwt_forward_batch(vw_ctx *ctx, const double *x, int64_t b, int64_t n, int32_t levels,
+                               const double *h, int32_t lh, const double *g, int32_t lg,
+                               int32_t boundary, uint32_t flags, double *coeffs,
+                               int64_t *first_bad);
+int32_t vw_modwt_forward_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
+                                   int32_t levels, const double *h, int32_t lh, const double *g,
+                                   int32_t lg, int32_t boundary, uint32_t flags,
+                                   double *coeffs_dev, int64_t *first_bad_dev, void *stream);
+
+/* ---- inverse ------------------------------------------------------------ */
+
+/* Batched J-level inverse MODWT.  Replaces MODWTTransform.inverse /
+ * inverseBatch / inverseBatchOptimized for J = 1 (modwt/MODWTTransform.java:
+ * 193-291, 504-532, 592-662) and MultiLevelMODWTTransform.reconstruct +
+ * reconstructSingleLevel + applyScaledInverseMODWT for J >= 1
+ * (modwt/MultiLevelMODWTTransform.java:362-375, 543-553, 621-689).
+ *   coeffs [B][J+1][N] in, x [B][N] out; hr/gr = lowPass/highPassReconstruction().
+ *   PERIODIC / ZERO_PADDING loop l < lhr and index gr[l] like the reference, so
+ *   lgr >= lhr is required (VW_E_LENGTH_MISMATCH otherwise -- the reference
+ *   throws ArrayIndexOutOfBounds there); extra high-pass taps are ignored.
+ *   VW_FLAG_CHECK_FINITE checks the coefficients (MODWTResult.isValid,
+ *   modwt/MODWTTransform.java:196-207). */
+int32_t vw_modwt_inverse_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n,
+                               int32_t levels, const double *hr, int32_t lhr, const double *gr,
+                               int32_t lgr, int32_t boundary, uint32_t flags, double *x,
+                               int64_t *first_bad);
+int32_t vw_modwt_inverse_batch_dev(vw_ctx *ctx, const double *coeffs_dev, int64_t b, int64_t n,
+                                   int32_t levels, const double *hr, int32_t lhr, const double *gr,
+                                   int32_t lgr, int32_t boundary, uint32_t flags, double *x_dev,
+                                   int64_t *first_bad_dev, void *stream);
+
+/* Band-selective reconstruction: like vw_modwt_inverse_batch but band k of the
+ * coefficient block is treated as all zeros unless bit k of `band_mask` is set
+ * (bit 0 = d_1, ..., bit J-1 = d_J, bit J = a_J).  Replaces
+ * MultiLevelMODWTTransform.reconstructFromLevel / reconstructLevels
+ * (modwt/MultiLevelMODWTTransform.java:385-468) and
+ * VectorWaveSwtAdapter.extractLevel (swt/VectorWaveSwtAdapter.java:326-348). */
+int32_t vw_modwt_inverse_bands_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n,
+                                     int32_t levels, const double *hr, int32_t lhr,
+                                     const double *gr, int32_t lgr, int32_t boundary,
+                                     uint32_t band_mask, double *x);
+int32_t vw_modwt_inverse_bands_batch_dev(vw_ctx *ctx, const double *coeffs_dev, int64_t b,
+                                         int64_t n, int32_t levels, const double *hr, int32_t lhr,
+                                         const double *gr, int32_t lgr, int32_t boundary,
+                                         uint32_t band_mask, double *x_dev, void *stream);
+
+/* ---- SWT denoise -------------------------------------------------------- */
+
+/* Batched VectorWaveSwtAdapter.denoise(signal, levels, threshold, soft)
+ * (swt/VectorWaveSwtAdapter.java:282-312): decompose, threshold the detail
+ * bands 1..J (approximation untouched), reconstruct.
+ *   threshold < 0 selects the universal threshold per signal
+ *   (applyUniversalThreshold / estimateNoiseSigma, :255-270, :377-395):
+ *   sigma = median(|d_1|) / 0.6745 with the exact order statistics the
+ *   reference's sort yields (even N: mean of elements N/2-1 and N/2), thr =
+ *   sigma * sqrt_2_ln_n.  The host passes sqrt_2_ln_n = Math.sqrt(2 *
+ *   Math.log(N)) so that the transcendental is evaluated by the host's libm;
+ *   pass a negative value to let the library compute it with its own libm.
+ *   soft != 0: |c| > thr ? signum(c) * (|c| - thr) : 0.0; soft == 0: |c| <= thr
+ *   -> 0.0 (modwt/MutableMultiLevelMODWTResult.java:97-114).
+ *   x [B][N] in, y [B][N] out (may alias x).  thresholds_out (may be NULL)
+ *   receives the B thresholds used.
+ *   The _dev variant needs a scratch block for the coefficients: pass
+ *   workspace_dev/workspace_bytes >= vw_swt_denoise_workspace_bytes(...), or
+ *   NULL/0 to let the context allocate (and keep) one. */
+int32_t vw_swt_denoise_batch(vw_ctx *ctx, const double *x, int64_t b, int64_t n, int32_t levels,
+                             const double *h, int32_t lh, const double *g, int32_t lg,
+                             const double *hr, int32_t lhr, const double *gr, int32_t lgr,
+                             int32_t boundary, double threshold, double sqrt_2_ln_n, int32_t soft,
+                             double *y, double *thresholds_out);
+int32_t vw_swt_denoise_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
+                                 int32_t levels, const double *h, int32_t lh, const double *g,
+                                 int32_t lg, const double *hr, int32_t lhr, const double *gr,
+                                 int32_t lgr, int32_t boundary, double threshold,
+                                 double sqrt_2_ln_n, int32_t soft, double *y_dev,
+                                 double *thresholds_out_dev, void *workspace_dev,
+                                 size_t workspace_bytes, void *stream);
+size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
+
+/* Per-signal universal threshold of an existing decomposition
+ * (VectorWaveSwtAdapter.applyUniversalThreshold's threshold value,
+ * swt/VectorWaveSwtAdapter.java:255-264): thresholds[b] from band d_1 of
+ * coeffs [B][J+1][N]. */
+int32_t vw_swt_universal_threshold_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n,
+                                         int32_t levels, double sqrt_2_ln_n, double *thresholds);
+int32_t vw_swt_universal_threshold_batch_dev(vw_ctx *ctx, const double *coeffs_dev, int64_t b,
+                                             int64_t n, int32_t levels, double sqrt_2_ln_n,
+                                             double *thresholds_dev, void *stream);
+
+/* ---- thresholding ------------------------------------------------------- */
+
+/* Element-wise thresholding, out of place (out may alias in).  Replaces
+ * WaveletOperations.softThreshold / hardThreshold (WaveletOperations.java:
+ * 89-122 -> internal/VectorOps.java:448-539) and
+ * MutableMultiLevelMODWTResult.applyThreshold
+ * (modwt/MutableMultiLevelMODWTResult.java:83-114).  threshold < 0 ->
+ * VW_E_NOT_POSITIVE (the reference throws IllegalArgumentException). */
+int32_t vw_threshold(vw_ctx *ctx, const double *in, int64_t count, double threshold, int32_t soft,
+                     double *out);
+int32_t vw_threshold_dev(vw_ctx *ctx, const double *in_dev, int64_t count, double threshold,
+                         int32_t soft, double *out_dev, void *stream);
+
+/* ---- raw convolutions (the reference's own seam) ------------------------ */
+
+/* One filter over a batch of signals: out[b][t] = sum_l x[b][idx(t - l*2^(level-1))] * filter[l]
+ * with the boundary rule of `boundary`; the filter is used AS GIVEN (no 1/sqrt2).
+ * level = 1 is WaveletOperations.circularConvolveMODWT /
+ * zeroPaddingConvolveMODWT / symmetricConvolveMODWT (WaveletOperations.java:
+ * 25-49 -> internal/ScalarOps.java:671-724, 799-845); level > 1 with PERIODIC
+ * is ScalarOps.circularConvolveMODWTLevel (internal/ScalarOps.java:743-789),
+ * including its level - 1 >= 31 -> VW_E_TOO_LARGE check. */
+int32_t vw_modwt_convolve_batch(vw_ctx *ctx, const double *x, int64_t b, int64_t n,
+                                const double *filter, int32_t filter_len, int32_t level,
+                                int32_t boundary, double *out);
+int32_t vw_modwt_convolve_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
+                                    const double *filter, int32_t filter_len, int32_t level,
+                                    int32_t boundary, double *out_dev, void *stream);
+
+/* ---- validation --------------------------------------------------------- */
+
+/* ValidationUtils.validateFiniteValues (util/ValidationUtils.java:106-117):
+ * *first_bad = index of the first NaN/Inf in x[0..count), or -1.  Returns
+ * VW_E_NONFINITE when one is found. */
+int32_t vw_first_non_finite(vw_ctx *ctx, const double *x, int64_t count, int64_t *first_bad);
+int32_t vw_first_non_finite_dev(vw_ctx *ctx, const double *x_dev, int64_t count,
+                                int64_t *first_bad_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VWGPU_H */

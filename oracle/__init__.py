@@ -1,0 +1,3 @@
+"""CPU oracle for the MODWT/SWT hot path.  TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+vectorwave_amd package."""

@@ -1,0 +1,179 @@
+"""ctypes front-end of oracle/vw_oracle.c (the C restatement of the reference).
+
+TEST INFRASTRUCTURE ONLY.  See vw_oracle.c for the reference citations of each
+function.  `build()` compiles the shared object with gcc; `lib()` loads it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libvw_oracle.so")
+
+PERIODIC, ZERO_PADDING, SYMMETRIC = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "vw_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.vwo_estimate_noise_sigma.restype = C.c_double
+        _lib.vwo_universal_threshold.restype = C.c_double
+        _lib.vwo_first_non_finite.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _conv(fn, signal, filt):
+    s, f = _f64(signal), _f64(filt)
+    out = np.empty_like(s)
+    getattr(lib(), fn)(_p(s), C.c_int64(s.size), _p(f), C.c_int64(f.size), _p(out))
+    return out
+
+
+def circular_convolve(signal, filt):
+    return _conv("vwo_circular_convolve", signal, filt)
+
+
+def circular_convolve_scalar(signal, filt):
+    return _conv("vwo_circular_convolve_scalar", signal, filt)
+
+
+def circular_convolve_vector_order(signal, filt):
+    return _conv("vwo_circular_convolve_vector_order", signal, filt)
+
+
+def zero_padding_convolve(signal, filt):
+    return _conv("vwo_zero_padding_convolve", signal, filt)
+
+
+def symmetric_convolve(signal, filt):
+    return _conv("vwo_symmetric_convolve", signal, filt)
+
+
+def circular_convolve_level(signal, filt, level):
+    s, f = _f64(signal), _f64(filt)
+    out = np.empty_like(s)
+    st = lib().vwo_circular_convolve_level(_p(s), C.c_int64(s.size), _p(f), C.c_int64(f.size), _p(out), C.c_int(level))
+    if st != 0:
+        raise ValueError("VAL_TOO_LARGE")
+    return out
+
+
+def max_levels(n, filter_len):
+    return int(lib().vwo_max_levels(C.c_int64(n), C.c_int(filter_len)))
+
+
+def modwt_forward_batch(x, wavelet, boundary=PERIODIC):
+    """Single-level forward; returns coeffs [B][2][N] = (d_1, a_1)."""
+    x = _f64(x)
+    b, n = x.shape
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    out = np.empty((b, 2, n))
+    lib().vwo_modwt_forward_batch(_p(x), C.c_int64(b), C.c_int64(n), _p(h), C.c_int(h.size), _p(g),
+                                  C.c_int(g.size), C.c_int(boundary), _p(out))
+    return out
+
+
+def modwt_inverse_batch(coeffs, wavelet, boundary=PERIODIC, batch_variant=1):
+    c = _f64(coeffs)
+    b, two, n = c.shape
+    assert two == 2
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    out = np.empty((b, n))
+    lib().vwo_modwt_inverse_batch(_p(c), C.c_int64(b), C.c_int64(n), _p(hr), C.c_int(hr.size), _p(gr),
+                                  C.c_int(gr.size), C.c_int(boundary), C.c_int(batch_variant), _p(out))
+    return out
+
+
+def decompose_batch(x, wavelet, levels, boundary=PERIODIC):
+    """Multi-level forward; returns (status, coeffs [B][J+1][N] = d_1..d_J, a_J)."""
+    x = _f64(x)
+    b, n = x.shape
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    out = np.empty((b, levels + 1, n))
+    st = lib().vwo_multilevel_decompose_batch(_p(x), C.c_int64(b), C.c_int64(n), C.c_int(levels), _p(h),
+                                             C.c_int(h.size), _p(g), C.c_int(g.size), C.c_int(boundary),
+                                             _p(out))
+    return int(st), out
+
+
+def reconstruct_batch(coeffs, wavelet, boundary=PERIODIC):
+    c = _f64(coeffs)
+    b, jp1, n = c.shape
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    out = np.empty((b, n))
+    lib().vwo_multilevel_reconstruct_batch(_p(c), C.c_int64(b), C.c_int64(n), C.c_int(jp1 - 1), _p(hr),
+                                           C.c_int(hr.size), _p(gr), C.c_int(gr.size), C.c_int(boundary),
+                                           _p(out))
+    return out
+
+
+def swt_denoise_batch(x, wavelet, levels, threshold=-1.0, soft=True, boundary=PERIODIC):
+    x = _f64(x)
+    b, n = x.shape
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    out = np.empty((b, n))
+    st = lib().vwo_swt_denoise_batch(_p(x), C.c_int64(b), C.c_int64(n), C.c_int(levels), _p(h), C.c_int(h.size),
+                                    _p(g), C.c_int(g.size), _p(hr), C.c_int(hr.size), _p(gr), C.c_int(gr.size),
+                                    C.c_int(boundary), C.c_double(threshold), C.c_int(1 if soft else 0), _p(out))
+    return int(st), out
+
+
+def apply_threshold(coeffs, threshold, soft):
+    c = _f64(coeffs).copy()
+    lib().vwo_apply_threshold(_p(c), C.c_int64(c.size), C.c_double(threshold), C.c_int(1 if soft else 0))
+    return c
+
+
+def soft_threshold(coeffs, threshold):
+    c = _f64(coeffs)
+    out = np.empty_like(c)
+    lib().vwo_soft_threshold(_p(c), C.c_int64(c.size), C.c_double(threshold), _p(out))
+    return out
+
+
+def hard_threshold(coeffs, threshold):
+    c = _f64(coeffs)
+    out = np.empty_like(c)
+    lib().vwo_hard_threshold(_p(c), C.c_int64(c.size), C.c_double(threshold), _p(out))
+    return out
+
+
+def estimate_noise_sigma(coeffs):
+    c = _f64(coeffs)
+    return float(lib().vwo_estimate_noise_sigma(_p(c), C.c_int64(c.size)))
+
+
+def universal_threshold(finest_detail):
+    c = _f64(finest_detail)
+    return float(lib().vwo_universal_threshold(_p(c), C.c_int64(c.size)))
+
+
+def first_non_finite(x):
+    c = _f64(x)
+    return int(lib().vwo_first_non_finite(_p(c), C.c_int64(c.size)))

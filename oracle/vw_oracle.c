@@ -1,0 +1,513 @@
+/*
+ * vw_oracle.c -- CPU restatement of the reference's MODWT / SWT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library calls, links or
+ * loads this file; it exists so the HIP kernels can be checked against an
+ * independent statement of the reference's arithmetic.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * The reference (Prophetizo/VectorWave) is Java; a JVM is not available in the
+ * build image, so every function below restates one Java method and cites it
+ * (paths relative to src/main/java/ai/prophetizo/wavelet/).  Java evaluates
+ * `sum += a * b` as a rounded multiply followed by a rounded add, never as a
+ * fused multiply-add, so this file MUST be compiled with -ffp-contract=off and
+ * without -ffast-math.  Loops keep the reference's summation order.
+ *
+ * Parity pinning: the closed-form known-answer vectors in the reference's own
+ * unit tests are replayed against this file by tests/test_oracle_kat.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VWO_PERIODIC 0
+#define VWO_ZERO_PADDING 1
+#define VWO_SYMMETRIC 2
+
+#define VWO_MAX_DECOMPOSITION_LEVELS 10 /* modwt/MultiLevelMODWTTransform.java:101 */
+#define VWO_MAX_SAFE_SHIFT_BITS 31      /* modwt/MultiLevelMODWTTransform.java:114 */
+
+/* ------------------------------------------------------------------------ */
+/* index helpers                                                            */
+/* ------------------------------------------------------------------------ */
+
+/* util/MathUtils.java:31-52 */
+static int64_t symmetric_boundary_extension(int64_t idx, int64_t n) {
+    if (idx >= 0 && idx < n) return idx;
+    int64_t period = 2 * n;
+    idx = ((idx % period) + period) % period;
+    if (idx >= n) idx = period - idx - 1;
+    return idx;
+}
+
+/* internal/ScalarOps.java:704-717 */
+static int64_t circular_index(int64_t idx, int64_t n) {
+    if (idx >= 0 && idx < n) return idx;
+    if (idx < 0 && idx >= -n) return idx + n;
+    return ((idx % n) + n) % n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* a1..a4: the three convolutions + the dilated form                        */
+/* ------------------------------------------------------------------------ */
+
+/* internal/ScalarOps.java:694-724 (circularConvolveMODWTScalar) */
+void vwo_circular_convolve_scalar(const double *signal, int64_t n, const double *filter,
+                                  int64_t flen, double *output) {
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        for (int64_t l = 0; l < flen; l++) {
+            sum += signal[circular_index(t - l, n)] * filter[l];
+        }
+        output[t] = sum;
+    }
+}
+
+/* internal/VectorOps.java:554-649 (circularConvolveMODWTVectorized): tap-outer
+ * accumulation into a cleared output, taps equal to 0.0 skipped.  Per output
+ * element the products are added in the same ascending-l order as the scalar
+ * loop, so the values are identical; kept as a separate function because it is
+ * what the reference executes for N >= 128 and what the CPU baseline times. */
+void vwo_circular_convolve_vector_order(const double *signal, int64_t n, const double *filter,
+                                        int64_t flen, double *output) {
+    for (int64_t t = 0; t < n; t++) output[t] = 0.0;
+    for (int64_t l = 0; l < flen; l++) {
+        double f = filter[l];
+        if (f == 0.0) continue;
+        int64_t head = l < n ? l : n; /* outputs whose source index wraps */
+        for (int64_t t = 0; t < head; t++) output[t] += signal[circular_index(t - l, n)] * f;
+        for (int64_t t = head; t < n; t++) output[t] += signal[t - l] * f;
+    }
+}
+
+/* internal/ScalarOps.java:671-677 + :878-891 (dispatch with the Vector API on) */
+void vwo_circular_convolve(const double *signal, int64_t n, const double *filter, int64_t flen,
+                           double *output) {
+    int vector = 0;
+    if (n >= 32) vector = (n >= 128) || (flen <= 8);
+    if (vector)
+        vwo_circular_convolve_vector_order(signal, n, filter, flen, output);
+    else
+        vwo_circular_convolve_scalar(signal, n, filter, flen, output);
+}
+
+/* internal/ScalarOps.java:743-789 (circularConvolveMODWTLevel); returns 5
+ * (VAL_TOO_LARGE) when level-1 >= 31, else 0. */
+int vwo_circular_convolve_level(const double *signal, int64_t n, const double *filter,
+                                int64_t flen, double *output, int level) {
+    if (level - 1 >= VWO_MAX_SAFE_SHIFT_BITS) return 5;
+    int64_t shift = (int64_t)1 << (level - 1);
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        for (int64_t l = 0; l < flen; l++) {
+            sum += signal[circular_index(t - shift * l, n)] * filter[l];
+        }
+        output[t] = sum;
+    }
+    return 0;
+}
+
+/* internal/ScalarOps.java:799-817 */
+void vwo_zero_padding_convolve(const double *signal, int64_t n, const double *filter,
+                               int64_t flen, double *output) {
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        for (int64_t l = 0; l < flen; l++) {
+            int64_t idx = t - l;
+            if (idx >= 0 && idx < n) sum += signal[idx] * filter[l];
+        }
+        output[t] = sum;
+    }
+}
+
+/* internal/ScalarOps.java:827-845 */
+void vwo_symmetric_convolve(const double *signal, int64_t n, const double *filter, int64_t flen,
+                            double *output) {
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        for (int64_t l = 0; l < flen; l++) {
+            sum += signal[symmetric_boundary_extension(t - l, n)] * filter[l];
+        }
+        output[t] = sum;
+    }
+}
+
+/* modwt/MultiLevelMODWTTransform.java:840-864 (circularConvolveMODWTDirect) */
+static void circular_convolve_direct(const double *signal, int64_t n, const double *filter,
+                                     int64_t flen, double *output) {
+    int64_t eff = flen < n ? flen : n;
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        int64_t maxk = eff < t + 1 ? eff : t + 1;
+        for (int64_t k = 0; k < maxk; k++) sum += filter[k] * signal[t - k];
+        for (int64_t k = maxk; k < eff; k++) sum += filter[k] * signal[t - k + n];
+        output[t] = sum;
+    }
+}
+
+static void convolve_by_mode(const double *signal, int64_t n, const double *filter, int64_t flen,
+                             int boundary, double *output) {
+    if (boundary == VWO_PERIODIC)
+        vwo_circular_convolve(signal, n, filter, flen, output);
+    else if (boundary == VWO_ZERO_PADDING)
+        vwo_zero_padding_convolve(signal, n, filter, flen, output);
+    else
+        vwo_symmetric_convolve(signal, n, filter, flen, output);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a5 / a6: single-level transform                                          */
+/* ------------------------------------------------------------------------ */
+
+static double *scaled_copy(const double *taps, int len) {
+    /* modwt/MODWTTransform.java:133-142: scale = 1.0 / Math.sqrt(2.0); tap * scale */
+    double scale = 1.0 / sqrt(2.0);
+    double *out = (double *)malloc(sizeof(double) * (size_t)(len > 0 ? len : 1));
+    for (int i = 0; i < len; i++) out[i] = taps[i] * scale;
+    return out;
+}
+
+/* modwt/MODWTTransform.java:123-179 (forward); h/g are the wavelet's UNSCALED
+ * decomposition filters. */
+void vwo_modwt_forward(const double *x, int64_t n, const double *h, int lh, const double *g,
+                       int lg, int boundary, double *approx, double *detail) {
+    double *sh = scaled_copy(h, lh), *sg = scaled_copy(g, lg);
+    convolve_by_mode(x, n, sh, lh, boundary, approx);
+    convolve_by_mode(x, n, sg, lg, boundary, detail);
+    free(sh);
+    free(sg);
+}
+
+/* modwt/MODWTTransform.java:193-291 (inverse) and :592-662 (inverseBatchOptimized).
+ * The loop bound is the low-pass reconstruction length and the high-pass filter
+ * is indexed with the same l (the reference does this even when the lengths
+ * differ; callers must pass lgr >= lhr).  `batch_variant` selects the SYMMETRIC
+ * flavour: 0 = inverse() reflects t-l (:269-287), 1 = inverseBatchOptimized()
+ * reflects t+l (:644-657). */
+void vwo_modwt_inverse(const double *approx, const double *detail, int64_t n, const double *hr,
+                       int lhr, const double *gr, int lgr, int boundary, int batch_variant,
+                       double *out) {
+    double *lo = scaled_copy(hr, lhr), *hi = scaled_copy(gr, lgr);
+    for (int64_t t = 0; t < n; t++) {
+        double sum = 0.0;
+        for (int l = 0; l < lhr; l++) {
+            int64_t idx;
+            if (boundary == VWO_PERIODIC) {
+                idx = (t + l) % n;
+            } else if (boundary == VWO_ZERO_PADDING) {
+                idx = t + l;
+                if (idx >= n) continue;
+            } else if (!batch_variant) {
+                idx = symmetric_boundary_extension(t - l, n);
+            } else {
+                int64_t period = n << 1;
+                int64_t mod = (t + l) % period;
+                idx = mod < n ? mod : period - mod - 1;
+            }
+            sum += lo[l] * approx[idx] + hi[l] * detail[idx];
+        }
+        out[t] = sum;
+    }
+    free(lo);
+    free(hi);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a7 / a8: multi-level cascade                                             */
+/* ------------------------------------------------------------------------ */
+
+/* modwt/MultiLevelMODWTTransform.java:477-523 (calculateMaxLevels) */
+int vwo_max_levels(int64_t n, int filter_len) {
+    if (n <= filter_len) return 0;
+    int max_level = 1;
+    int64_t lm1 = filter_len - 1;
+    while (max_level < VWO_MAX_DECOMPOSITION_LEVELS) {
+        if (max_level - 1 >= VWO_MAX_SAFE_SHIFT_BITS) break;
+        int64_t scaled = lm1 * ((int64_t)1 << (max_level - 1)) + 1;
+        if (scaled > n) break;
+        max_level++;
+    }
+    return max_level - 1;
+}
+
+/* modwt/MultiLevelMODWTTransform.java:697-752 and :560-615: zero-stuff by
+ * 2^(level-1) and scale every tap by 1/sqrt(2).  Returns malloc'd filter. */
+static double *stuffed_filter(const double *taps, int len, int level, int64_t *out_len) {
+    double scale = 1.0 / sqrt(2.0);
+    int64_t up = (int64_t)1 << (level - 1);
+    int64_t flen = (int64_t)(len - 1) * up + 1;
+    double *f = (double *)calloc((size_t)flen, sizeof(double));
+    for (int i = 0; i < len; i++) f[(int64_t)i * up] = taps[i] * scale;
+    *out_len = flen;
+    return f;
+}
+
+/* modwt/MultiLevelMODWTTransform.java:793-834 (applyScaledMODWT) */
+static void apply_scaled_modwt(const double *signal, int64_t n, const double *lo, int64_t lo_len,
+                               const double *hi, int64_t hi_len, int boundary, double *approx,
+                               double *detail) {
+    /* :801-806 truncation (getTruncatedFilter keeps the first n entries) */
+    if (lo_len > n) lo_len = n;
+    if (hi_len > n) hi_len = n;
+    if (boundary == VWO_PERIODIC) {
+        if (n < 64 || lo_len > n / 2) {
+            circular_convolve_direct(signal, n, lo, lo_len, approx);
+            circular_convolve_direct(signal, n, hi, hi_len, detail);
+        } else {
+            vwo_circular_convolve(signal, n, lo, lo_len, approx);
+            vwo_circular_convolve(signal, n, hi, hi_len, detail);
+        }
+    } else if (boundary == VWO_ZERO_PADDING) {
+        vwo_zero_padding_convolve(signal, n, lo, lo_len, approx);
+        vwo_zero_padding_convolve(signal, n, hi, hi_len, detail);
+    } else {
+        vwo_symmetric_convolve(signal, n, lo, lo_len, approx);
+        vwo_symmetric_convolve(signal, n, hi, hi_len, detail);
+    }
+}
+
+/* modwt/MultiLevelMODWTTransform.java:214-268 (decompose) / :299-353.
+ * coeffs is [levels+1][n]: d_1 .. d_J, a_J.  Returns 0, or 104
+ * (CFG_INVALID_DECOMPOSITION_LEVEL) / 6 (VAL_EMPTY) like the reference's checks. */
+int vwo_multilevel_decompose(const double *x, int64_t n, int levels, const double *h, int lh,
+                             const double *g, int lg, int boundary, double *coeffs) {
+    if (n == 0) return 6;
+    int max_levels = vwo_max_levels(n, lh);
+    if (levels < 1 || levels > max_levels) return 104;
+    double *cur = (double *)malloc(sizeof(double) * (size_t)n);
+    double *next = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(cur, x, sizeof(double) * (size_t)n);
+    for (int level = 1; level <= levels; level++) {
+        int64_t lo_len, hi_len;
+        double *lo = stuffed_filter(h, lh, level, &lo_len);
+        double *hi = stuffed_filter(g, lg, level, &hi_len);
+        apply_scaled_modwt(cur, n, lo, lo_len, hi, hi_len, boundary, next,
+                           coeffs + (int64_t)(level - 1) * n);
+        free(lo);
+        free(hi);
+        double *tmp = cur;
+        cur = next;
+        next = tmp;
+    }
+    memcpy(coeffs + (int64_t)levels * n, cur, sizeof(double) * (size_t)n);
+    free(cur);
+    free(next);
+    return 0;
+}
+
+/* modwt/MultiLevelMODWTTransform.java:621-689 (applyScaledInverseMODWT), dense
+ * over the zero-stuffed filters exactly as the reference iterates them. */
+static void apply_scaled_inverse(const double *approx, const double *details, int64_t n,
+                                 const double *lo, int64_t lo_len, const double *hi,
+                                 int64_t hi_len, int boundary, double *out) {
+    if (lo_len > n) lo_len = n; /* :628-636 truncation */
+    if (hi_len > n) hi_len = n;
+    if (boundary == VWO_PERIODIC) {
+        for (int64_t t = 0; t < n; t++) {
+            double sum = 0.0;
+            for (int64_t l = 0; l < lo_len; l++) {
+                int64_t idx = (t + l) % n;
+                sum += lo[l] * approx[idx] + hi[l] * details[idx];
+            }
+            out[t] = sum;
+        }
+    } else if (boundary == VWO_ZERO_PADDING) {
+        for (int64_t t = 0; t < n; t++) {
+            double sum = 0.0;
+            for (int64_t l = 0; l < lo_len; l++) {
+                int64_t idx = t + l;
+                if (idx < n) sum += lo[l] * approx[idx] + hi[l] * details[idx];
+            }
+            out[t] = sum;
+        }
+    } else {
+        int64_t max_len = lo_len > hi_len ? lo_len : hi_len;
+        for (int64_t t = 0; t < n; t++) {
+            double sum = 0.0;
+            for (int64_t l = 0; l < max_len; l++) {
+                int64_t idx = symmetric_boundary_extension(t - l, n);
+                if (l < lo_len) sum += lo[l] * approx[idx];
+                if (l < hi_len) sum += hi[l] * details[idx];
+            }
+            out[t] = sum;
+        }
+    }
+}
+
+/* modwt/MultiLevelMODWTTransform.java:362-375 (reconstruct).  hr/gr: UNSCALED
+ * reconstruction filters; for PERIODIC / ZERO_PADDING the reference indexes
+ * gr[l] for l < len(hr-stuffed), so lgr >= lhr is required (equal for every
+ * orthogonal wavelet). */
+void vwo_multilevel_reconstruct(const double *coeffs, int64_t n, int levels, const double *hr,
+                                int lhr, const double *gr, int lgr, int boundary, double *out) {
+    double *rec = (double *)malloc(sizeof(double) * (size_t)n);
+    double *next = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(rec, coeffs + (int64_t)levels * n, sizeof(double) * (size_t)n);
+    for (int level = levels; level >= 1; level--) {
+        int64_t lo_len, hi_len;
+        double *lo = stuffed_filter(hr, lhr, level, &lo_len);
+        double *hi = stuffed_filter(gr, lgr, level, &hi_len);
+        apply_scaled_inverse(rec, coeffs + (int64_t)(level - 1) * n, n, lo, lo_len, hi, hi_len,
+                             boundary, next);
+        free(lo);
+        free(hi);
+        double *tmp = rec;
+        rec = next;
+        next = tmp;
+    }
+    memcpy(out, rec, sizeof(double) * (size_t)n);
+    free(rec);
+    free(next);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a10 / a11: thresholds, universal threshold, SWT denoise                  */
+/* ------------------------------------------------------------------------ */
+
+/* modwt/MutableMultiLevelMODWTResult.java:97-114 (applyThresholdToArray), in place */
+void vwo_apply_threshold(double *c, int64_t n, double threshold, int soft) {
+    for (int64_t i = 0; i < n; i++) {
+        double a = fabs(c[i]);
+        if (soft) {
+            if (a > threshold) {
+                double sg = c[i] > 0.0 ? 1.0 : (c[i] < 0.0 ? -1.0 : c[i]); /* Math.signum */
+                c[i] = sg * (a - threshold);
+            } else {
+                c[i] = 0.0;
+            }
+        } else if (a <= threshold) {
+            c[i] = 0.0;
+        }
+    }
+}
+
+/* internal/VectorOps.java:448-497 (scalar branch :454-459), out of place */
+void vwo_soft_threshold(const double *c, int64_t n, double threshold, double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        double a = fabs(c[i]);
+        double sg = c[i] > 0.0 ? 1.0 : (c[i] < 0.0 ? -1.0 : c[i]);
+        out[i] = a <= threshold ? 0.0 : sg * (a - threshold);
+    }
+}
+
+/* internal/VectorOps.java:502-539 */
+void vwo_hard_threshold(const double *c, int64_t n, double threshold, double *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = fabs(c[i]) <= threshold ? 0.0 : c[i];
+}
+
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/* swt/VectorWaveSwtAdapter.java:377-395 (estimateNoiseSigma) */
+double vwo_estimate_noise_sigma(const double *coeffs, int64_t n) {
+    double *a = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) a[i] = fabs(coeffs[i]);
+    qsort(a, (size_t)n, sizeof(double), cmp_double);
+    double median;
+    if (n % 2 == 0)
+        median = (a[n / 2 - 1] + a[n / 2]) / 2.0;
+    else
+        median = a[n / 2];
+    free(a);
+    return median / 0.6745;
+}
+
+/* swt/VectorWaveSwtAdapter.java:255-270: threshold = sigma * Math.sqrt(2 * Math.log(n)) */
+double vwo_universal_threshold(const double *finest_detail, int64_t n) {
+    double sigma = vwo_estimate_noise_sigma(finest_detail, n);
+    return sigma * sqrt(2 * log((double)n));
+}
+
+/* swt/VectorWaveSwtAdapter.java:296-312 (denoise).  threshold < 0 selects the
+ * universal threshold.  Returns the status of the decomposition. */
+int vwo_swt_denoise(const double *x, int64_t n, int levels, const double *h, int lh,
+                    const double *g, int lg, const double *hr, int lhr, const double *gr, int lgr,
+                    int boundary, double threshold, int soft, double *out) {
+    double *coeffs = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(levels + 1));
+    int st = vwo_multilevel_decompose(x, n, levels, h, lh, g, lg, boundary, coeffs);
+    if (st != 0) {
+        free(coeffs);
+        return st;
+    }
+    double thr = threshold < 0 ? vwo_universal_threshold(coeffs, n) : threshold;
+    for (int level = 1; level <= levels; level++)
+        vwo_apply_threshold(coeffs + (int64_t)(level - 1) * n, n, thr, soft);
+    vwo_multilevel_reconstruct(coeffs, n, levels, hr, lhr, gr, lgr, boundary, out);
+    free(coeffs);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* batch drivers (row loops, OpenMP over signals) used by tests + cpu_baseline */
+/* ------------------------------------------------------------------------ */
+
+/* modwt/MODWTTransform.java:537-587: `for b` loop, output [B][2][N] = (d_1, a_1) */
+void vwo_modwt_forward_batch(const double *x, int64_t b, int64_t n, const double *h, int lh,
+                             const double *g, int lg, int boundary, double *coeffs) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++)
+        vwo_modwt_forward(x + i * n, n, h, lh, g, lg, boundary, coeffs + (i * 2 + 1) * n,
+                          coeffs + (i * 2) * n);
+}
+
+/* modwt/MODWTTransform.java:592-662 */
+void vwo_modwt_inverse_batch(const double *coeffs, int64_t b, int64_t n, const double *hr, int lhr,
+                             const double *gr, int lgr, int boundary, int batch_variant,
+                             double *x) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++)
+        vwo_modwt_inverse(coeffs + (i * 2 + 1) * n, coeffs + (i * 2) * n, n, hr, lhr, gr, lgr,
+                          boundary, batch_variant, x + i * n);
+}
+
+int vwo_multilevel_decompose_batch(const double *x, int64_t b, int64_t n, int levels,
+                                   const double *h, int lh, const double *g, int lg, int boundary,
+                                   double *coeffs) {
+    int status = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++) {
+        int st = vwo_multilevel_decompose(x + i * n, n, levels, h, lh, g, lg, boundary,
+                                          coeffs + i * (levels + 1) * n);
+        if (st != 0) {
+#pragma omp critical
+            status = st;
+        }
+    }
+    return status;
+}
+
+void vwo_multilevel_reconstruct_batch(const double *coeffs, int64_t b, int64_t n, int levels,
+                                      const double *hr, int lhr, const double *gr, int lgr,
+                                      int boundary, double *x) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++)
+        vwo_multilevel_reconstruct(coeffs + i * (levels + 1) * n, n, levels, hr, lhr, gr, lgr,
+                                   boundary, x + i * n);
+}
+
+int vwo_swt_denoise_batch(const double *x, int64_t b, int64_t n, int levels, const double *h,
+                          int lh, const double *g, int lg, const double *hr, int lhr,
+                          const double *gr, int lgr, int boundary, double threshold, int soft,
+                          double *out) {
+    int status = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++) {
+        int st = vwo_swt_denoise(x + i * n, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary,
+                                 threshold, soft, out + i * n);
+        if (st != 0) {
+#pragma omp critical
+            status = st;
+        }
+    }
+    return status;
+}
+
+/* util/ValidationUtils.java:106-117: index of the first NaN/Inf, or -1 */
+int64_t vwo_first_non_finite(const double *x, int64_t n) {
+    for (int64_t i = 0; i < n; i++)
+        if (!isfinite(x[i])) return i;
+    return -1;
+}

@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Bar: bit-for-bit (the kernels round every product and
+sum separately and add taps in the reference's order)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from vectorwave_amd import _native as N
+from vectorwave_amd.wavelets import get_wavelet
+
+from util import P, S, Z, assert_bits_equal, gpu_denoise, gpu_forward, gpu_inverse, signals
+
+pytestmark = pytest.mark.gpu
+
+MODES = [P, Z, S]
+
+# (wavelet, N, J or None for max, B)
+ML_CASES = [
+    ("haar", 8, 3, 2), ("haar", 7, 2, 3), ("haar", 64, 5, 2), ("db2", 64, 3, 3), ("db4", 64, 3, 2),
+    ("db4", 777, None, 3), ("db4", 1000, 3, 5), ("db4", 1024, 6, 4), ("db4", 4096, 6, 3), ("db4", 4100, 6, 2),
+    ("db4", 5001, 5, 2), ("db4", 16384, 6, 2), ("db10", 1000, 4, 2), ("sym8", 4096, 8, 2), ("coif3", 777, 5, 2),
+    ("db10", 9999, 8, 2), ("sym8", 12288, 8, 1), ("bior4.4", 500, 4, 2), ("bior1.3", 300, 3, 2), ("bior2.2", 257, 4, 2),
+    ("rbio1.3", 40, 4, 2), ("rbio2.4", 100, 5, 2), ("dmey", 2000, 5, 1), ("coif17", 4000, 5, 1), ("db20", 3000, 6, 1),
+]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("wn,n,j,b", ML_CASES)
+def test_multilevel_forward_inverse_bit_exact(ctx, wn, n, j, b, mode):
+    w = get_wavelet(wn)
+    if j is None:
+        j = o.max_levels(n, len(w.dec_lo))
+    x = signals(b, n, seed=n + j)
+    st, want = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    st, got, _ = gpu_forward(ctx, x, wn, j, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "forward %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    if len(w.rec_hi) < len(w.rec_lo) and mode != S:
+        st, _, _ = gpu_inverse(ctx, want, wn, mode)
+        assert st == N.VW_E_LENGTH_MISMATCH  # the reference indexes out of bounds here
+        return
+    wantx = o.reconstruct_batch(want, w, mode)
+    st, gotx, _ = gpu_inverse(ctx, want, wn, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(gotx, wantx, "inverse %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    if mode == P and w.orthogonal and wn != "dmey":
+        # reconstruction vs the reference's reconstruction is exact; vs the input it is
+        # bounded by the tap tables' own orthogonality error
+        tol = 1e-10 if wn in ("haar", "db2", "db4") else 1e-3
+        assert np.abs(gotx - x).max() < tol * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("wn", ["haar", "db4", "sym8", "bior4.4"])
+@pytest.mark.parametrize("n,b", [(1, 2), (5, 3), (8, 1), (63, 4), (64, 4), (1000, 32), (2049, 2)])
+def test_single_level_bit_exact(ctx, wn, n, b, mode):
+    # BASELINE config 1 is the (1000, 32) DB4 PERIODIC case
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=n)
+    want = o.modwt_forward_batch(x, w, mode)
+    st, got, _ = gpu_forward(ctx, x, wn, 1, mode, N.VW_FLAG_SINGLE_LEVEL)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "single forward")
+    for variant, flag in ((0, 0), (1, N.VW_FLAG_SYMMETRIC_BATCH_VARIANT)):
+        wantx = o.modwt_inverse_batch(want, w, mode, batch_variant=variant)
+        st, gotx, _ = gpu_inverse(ctx, want, wn, mode, N.VW_FLAG_SINGLE_LEVEL | flag)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(gotx, wantx, "single inverse variant %d" % variant)
+
+
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("soft", [True, False])
+@pytest.mark.parametrize("wn,n,j,b,thr", [("db4", 480, 4, 64, -1.0), ("haar", 480, 4, 16, -1.0), ("db4", 256, 4, 8, -999.0),
+                                          ("db4", 481, 3, 8, -1.0), ("sym8", 4097, 5, 3, -1.0), ("db4", 9000, 6, 2, -1.0),
+                                          ("db4", 480, 4, 8, 0.25), ("coif3", 1000, 3, 4, 0.0)])
+def test_swt_denoise_bit_exact(ctx, wn, n, j, b, thr, soft, mode):
+    # BASELINE config 5 shape: J=4 universal soft threshold on 480-sample blocks
+    w = get_wavelet(wn)
+    t = np.arange(n)
+    rng = np.random.default_rng(n + j)
+    x = np.ascontiguousarray(np.sin(2 * np.pi * t / 32.0)[None] + 0.5 * rng.standard_normal((b, n)))
+    st, want = o.swt_denoise_batch(x, w, j, thr, soft, mode)
+    assert st == 0
+    st, got, thrs = gpu_denoise(ctx, x, wn, j, mode, thr, soft)
+    assert st == 0, ctx.last_error()
+    if thr < 0:
+        st, c = o.decompose_batch(x, w, j, mode)
+        want_thr = np.array([o.universal_threshold(c[i, 0]) for i in range(b)])
+        assert_bits_equal(thrs, want_thr, "universal thresholds")
+    assert_bits_equal(got, want, "denoise")
+
+
+def test_median_with_duplicates_and_zeros(ctx):
+    # even N with duplicated middle elements, all-zero band, odd N
+    lib = ctx.lib
+    for n, fill in ((10, None), (10, 0.0), (11, None), (4096, None), (4098, None), (70000, None)):
+        rng = np.random.default_rng(n)
+        d1 = np.round(rng.standard_normal((3, n)), 1) if fill is None else np.full((3, n), fill)
+        coeffs = np.zeros((3, 2, n))
+        coeffs[:, 0] = d1
+        thr = np.empty(3)
+        s2 = math.sqrt(2 * math.log(n))
+        st = lib.vw_swt_universal_threshold_batch(ctx.handle, C.c_void_p(coeffs.ctypes.data), 3, n, 1, s2,
+                                                  C.c_void_p(thr.ctypes.data))
+        assert st == 0, ctx.last_error()
+        want = np.array([o.universal_threshold(d1[i]) for i in range(3)])
+        assert_bits_equal(thr, want, "median n=%d" % n)
+
+
+def test_thresholds_and_raw_convolutions(ctx):
+    from vectorwave_amd import WaveletOperations as W
+    c = signals(1, 1001, seed=1)[0]
+    assert_bits_equal(W.softThreshold(c, 0.3, ctx), o.soft_threshold(c, 0.3), "soft")
+    assert_bits_equal(W.hardThreshold(c, 0.3, ctx), o.hard_threshold(c, 0.3), "hard")
+    with pytest.raises(ValueError):
+        W.softThreshold(c, -1.0, ctx)
+    # internal/ScalarOpsTest.java:225-274, :245-258
+    np.testing.assert_allclose(W.circularConvolveMODWT([1, 2, 3, 4], [0.6, 0.4], None, ctx), [2.2, 1.6, 2.6, 3.6], atol=1e-12)
+    np.testing.assert_allclose(W.zeroPaddingConvolveMODWT([1, 2, 3, 4], [0.6, 0.4], None, ctx), [0.6, 1.6, 2.6, 3.6], atol=1e-12)
+    out = W.circularConvolveMODWTLevel(np.arange(1.0, 9.0), [0.7, 0.3], None, 2, ctx)
+    assert abs(out[0] - (1 * 0.7 + 7 * 0.3)) < 1e-10 and abs(out[1] - (2 * 0.7 + 8 * 0.3)) < 1e-10
+    x = signals(1, 300, seed=4)[0]
+    f = np.asarray(get_wavelet("db4").dec_lo)
+    assert_bits_equal(W.circularConvolveMODWT(x, f, None, ctx), o.circular_convolve(x, f), "circ")
+    assert_bits_equal(W.zeroPaddingConvolveMODWT(x, f, None, ctx), o.zero_padding_convolve(x, f), "zero")
+    assert_bits_equal(W.symmetricConvolveMODWT(x, f, None, ctx), o.symmetric_convolve(x, f), "sym")
+    assert_bits_equal(W.circularConvolveMODWTLevel(x, f, None, 3, ctx), o.circular_convolve_level(x, f, 3), "level")
+    # sparse filter (internal/VectorOpsTest.java:453-464)
+    assert_bits_equal(W.circularConvolveMODWT(x, [0.5, 0.0, 0.5, 0.0], None, ctx),
+                      o.circular_convolve(x, [0.5, 0.0, 0.5, 0.0]), "sparse")
+
+
+def test_status_codes(ctx):
+    x = signals(2, 64)
+    # levels 0 / 20 rejected (modwt/MultiLevelMODWTTransformTest.java:203-218)
+    assert gpu_forward(ctx, x, "haar", 0, P)[0] == N.VW_E_LEVEL
+    assert gpu_forward(ctx, x, "haar", 20, P)[0] == N.VW_E_LEVEL
+    assert gpu_forward(ctx, x, "db4", 4, P)[0] == 0  # (8-1)*8+1 = 57 <= 64
+    assert gpu_forward(ctx, x, "db4", 5, P)[0] == N.VW_E_LEVEL  # (8-1)*16+1 = 113 > 64
+    assert gpu_forward(ctx, x, "haar", 2, 7)[0] == N.VW_E_BOUNDARY
+    # NaN detection with the first bad flat index (util/ValidationUtils.java:106-117)
+    xb = x.copy()
+    xb[1, 5] = np.nan
+    xb[1, 9] = np.inf
+    st, _, bad = gpu_forward(ctx, xb, "haar", 2, P, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == 64 + 5
+    st, _, bad = gpu_forward(ctx, x, "haar", 2, P, N.VW_FLAG_CHECK_FINITE)
+    assert st == 0 and bad == -1
+    st, c = o.decompose_batch(x, get_wavelet("haar"), 2, P)
+    c[0, 1, 3] = np.inf
+    st, _, bad = gpu_inverse(ctx, c, "haar", P, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == 64 + 3
+    # empty batch / empty signal
+    st, _, _ = gpu_forward(ctx, np.zeros((0, 64)), "haar", 2, P)
+    assert st == 0
+    st, _, _ = gpu_forward(ctx, np.zeros((2, 0)), "haar", 1, P, N.VW_FLAG_SINGLE_LEVEL)
+    assert st == N.VW_E_EMPTY

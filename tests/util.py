@@ -1,0 +1,78 @@
+"""Shared helpers for the parity tests."""
+import ctypes as C
+import math
+
+import numpy as np
+
+from vectorwave_amd import _native as N
+from vectorwave_amd.wavelets import get_wavelet
+
+P, Z, S = 0, 1, 2
+
+
+def signals(b, n, seed=42):
+    """sin(2*pi*t/32) + 0.5*sin(2*pi*t/64) + 0.1*N(0,1): the shape of the reference's
+    benchmark generator (src/test/.../swt/SWTBenchmarkTest.java:230-238)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    base = np.sin(2 * np.pi * t / 32.0) + 0.5 * np.sin(2 * np.pi * t / 64.0)
+    return np.ascontiguousarray(base[None, :] + 0.1 * rng.standard_normal((b, n)))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _t(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def gpu_forward(ctx, x, wname, levels, boundary, flags=0):
+    w = get_wavelet(wname)
+    h, g = _t(w.dec_lo), _t(w.dec_hi)
+    b, n = x.shape
+    out = np.full((b, levels + 1, n), np.nan)
+    bad = C.c_int64(-7)
+    st = ctx.lib.vw_modwt_forward_batch(ctx.handle, _vp(x), b, n, levels, _dp(h), h.size, _dp(g), g.size, boundary,
+                                        flags, _vp(out), C.byref(bad))
+    return st, out, bad.value
+
+
+def gpu_inverse(ctx, coeffs, wname, boundary, flags=0):
+    w = get_wavelet(wname)
+    hr, gr = _t(w.rec_lo), _t(w.rec_hi)
+    b, jp1, n = coeffs.shape
+    out = np.full((b, n), np.nan)
+    bad = C.c_int64(-7)
+    st = ctx.lib.vw_modwt_inverse_batch(ctx.handle, _vp(coeffs), b, n, jp1 - 1, _dp(hr), hr.size, _dp(gr), gr.size,
+                                        boundary, flags, _vp(out), C.byref(bad))
+    return st, out, bad.value
+
+
+def gpu_denoise(ctx, x, wname, levels, boundary, threshold, soft):
+    w = get_wavelet(wname)
+    h, g, hr, gr = _t(w.dec_lo), _t(w.dec_hi), _t(w.rec_lo), _t(w.rec_hi)
+    b, n = x.shape
+    out = np.full((b, n), np.nan)
+    thr = np.full(b, np.nan)
+    st = ctx.lib.vw_swt_denoise_batch(ctx.handle, _vp(x), b, n, levels, _dp(h), h.size, _dp(g), g.size, _dp(hr),
+                                      hr.size, _dp(gr), gr.size, boundary, float(threshold),
+                                      math.sqrt(2 * math.log(n)), 1 if soft else 0, _vp(out), _vp(thr))
+    return st, out, thr
+
+
+def assert_bits_equal(a, b, what=""):
+    """Bit-for-bit equality of two float64 arrays (NaN payloads and zero signs included)."""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ai, bi = a.view(np.uint64), b.view(np.uint64)
+    if not np.array_equal(ai, bi):
+        idx = np.argwhere(ai != bi)
+        first = tuple(idx[0])
+        raise AssertionError("%s: %d of %d elements differ; first at %s: got %r (%s) want %r (%s)" % (
+            what, idx.shape[0], a.size, first, a[first], float(a[first]).hex(), b[first], float(b[first]).hex()))

@@ -1,0 +1,16 @@
+"""vectorwave_amd: MI355X-native batched MODWT / SWT engine.
+
+Host mirror of the reference's MODWTTransform / MultiLevelMODWTTransform /
+VectorWaveSwtAdapter API over libvwgpu.so (hand-written gfx950 HIP kernels
+behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
+"""
+from .api import (BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult, MODWTTransform,
+                  MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult,
+                  VectorWaveSwtAdapter, WaveletOperations, WaveletTransformException)
+from .wavelets import Wavelet, available_wavelets, get_wavelet
+
+__all__ = [
+    "BoundaryMode", "InvalidArgumentException", "InvalidSignalException", "MODWTResult", "MODWTTransform",
+    "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
+    "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
+]

@@ -1,0 +1,151 @@
+"""ctypes binding of libvwgpu.so (the C ABI declared in include/vwgpu.h).
+
+The library is the only compute path of this package: if it cannot be loaded,
+or no HIP device is present when a context is requested, the failure is raised
+to the caller.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvwgpu.so")
+
+# status codes (include/vwgpu.h)
+VW_OK = 0
+VW_E_NULL = 1
+VW_E_NONFINITE = 3
+VW_E_NOT_POSITIVE = 4
+VW_E_TOO_LARGE = 5
+VW_E_EMPTY = 6
+VW_E_LENGTH_MISMATCH = 7
+VW_E_BOUNDARY = 103
+VW_E_LEVEL = 104
+VW_E_NO_DEVICE = 900
+VW_E_HIP = 901
+VW_E_NOMEM = 902
+VW_E_WORKSPACE = 903
+
+VW_FLAG_CHECK_FINITE = 1
+VW_FLAG_SYMMETRIC_BATCH_VARIANT = 2
+VW_FLAG_NO_LEVEL_CHECK = 4
+VW_FLAG_SINGLE_LEVEL = 8
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol of include/vwgpu.h
+SIGNATURES = {
+    "vw_init": (C.c_int32, [C.c_int32, C.POINTER(_vp)]),
+    "vw_destroy": (C.c_int32, [_vp]),
+    "vw_last_error": (C.c_char_p, [_vp]),
+    "vw_performance_info": (C.c_char_p, [_vp]),
+    "vw_synchronize": (C.c_int32, [_vp]),
+    "vw_device_count": (C.c_int32, []),
+    "vw_max_levels": (C.c_int32, [C.c_int64, C.c_int32]),
+    "vw_modwt_forward_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                           C.c_int32, C.c_uint32, _vp, _i64p]),
+    "vw_modwt_forward_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp,
+                                               C.c_int32, C.c_int32, C.c_uint32, _vp, _vp, _vp]),
+    "vw_modwt_inverse_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                           C.c_int32, C.c_uint32, _vp, _i64p]),
+    "vw_modwt_inverse_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp,
+                                               C.c_int32, C.c_int32, C.c_uint32, _vp, _vp, _vp]),
+    "vw_modwt_inverse_bands_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp,
+                                                 C.c_int32, C.c_int32, C.c_uint32, _vp]),
+    "vw_modwt_inverse_bands_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp,
+                                                     C.c_int32, C.c_int32, C.c_uint32, _vp, _vp]),
+    "vw_swt_denoise_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                         _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                         _vp, _vp]),
+    "vw_swt_denoise_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                             _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                             C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "vw_swt_denoise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),
+    "vw_swt_universal_threshold_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp,
+                                                         _vp]),
+    "vw_threshold": (C.c_int32, [_vp, _vp, C.c_int64, C.c_double, C.c_int32, _vp]),
+    "vw_threshold_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_double, C.c_int32, _vp, _vp]),
+    "vw_modwt_convolve_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32,
+                                            _vp]),
+    "vw_modwt_convolve_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, C.c_int32, C.c_int32,
+                                                _vp, _vp]),
+    "vw_first_non_finite": (C.c_int32, [_vp, _vp, C.c_int64, _i64p]),
+    "vw_first_non_finite_dev": (C.c_int32, [_vp, _vp, C.c_int64, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    """libvwgpu.so is missing or no GPU is usable.  Never swallowed: the package has no CPU path."""
+
+
+def load():
+    """Load libvwgpu.so and declare every prototype.  Raises NativeLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s not found: build it with `make -C vectorwave_amd/csrc` (hipcc, gfx950). "
+            "vectorwave_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing HIP runtime etc.
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One vw_ctx: a HIP device plus the library-owned staging buffers and stream."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _vp()
+        st = self.lib.vw_init(int(device), C.byref(h))
+        if st != VW_OK:
+            raise NativeLibraryError(
+                "vw_init(device=%d) failed with status %d: no usable HIP device. "
+                "vectorwave_amd has no CPU fallback." % (device, st))
+        self.handle = h
+        self.device = device
+
+    def last_error(self) -> str:
+        return self.lib.vw_last_error(self.handle).decode()
+
+    def performance_info(self) -> str:
+        return self.lib.vw_performance_info(self.handle).decode()
+
+    def synchronize(self):
+        return self.lib.vw_synchronize(self.handle)
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            self.lib.vw_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[device] = ctx
+    return ctx

@@ -1,0 +1,698 @@
+"""Host-side mirror of the reference's MODWT / SWT API over the C ABI.
+
+Same class and method names, argument meaning and error behaviour as the
+reference's Java classes, so that parity tests read like the reference's own
+tests.  Every method that computes goes through libvwgpu.so (include/vwgpu.h);
+nothing here computes a transform on the CPU.
+
+Reference classes mirrored (paths under src/main/java/ai/prophetizo/wavelet/):
+  modwt/MODWTTransform.java:69            -> MODWTTransform
+  modwt/MultiLevelMODWTTransform.java:66  -> MultiLevelMODWTTransform
+  swt/VectorWaveSwtAdapter.java:61        -> VectorWaveSwtAdapter
+  WaveletOperations.java:12               -> WaveletOperations
+  modwt/MODWTResult.java:24, modwt/MultiLevelMODWTResult.java:24,
+  modwt/MutableMultiLevelMODWTResult.java:19 -> result containers
+  exception/ErrorCode.java:18             -> ErrorCode strings on the exceptions
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .wavelets import Wavelet, get_wavelet
+
+
+class BoundaryMode(enum.IntEnum):
+    """Boundary modes the MODWT classes accept (modwt/MODWTTransform.java:88-90)."""
+
+    PERIODIC = 0
+    ZERO_PADDING = 1
+    SYMMETRIC = 2
+
+
+class WaveletTransformException(Exception):
+    def __init__(self, message, error_code=None):
+        super().__init__(message)
+        self.error_code = error_code
+
+    def getErrorCode(self):
+        return self.error_code
+
+
+class InvalidSignalException(WaveletTransformException):
+    """exception/InvalidSignalException.java"""
+
+
+class InvalidArgumentException(WaveletTransformException):
+    """exception/InvalidArgumentException.java"""
+
+
+_STATUS_TO_CODE = {
+    N.VW_E_NULL: "VAL_001",
+    N.VW_E_NONFINITE: "VAL_003",
+    N.VW_E_NOT_POSITIVE: "VAL_004",
+    N.VW_E_TOO_LARGE: "VAL_005",
+    N.VW_E_EMPTY: "VAL_006",
+    N.VW_E_LENGTH_MISMATCH: "VAL_007",
+    N.VW_E_BOUNDARY: "CFG_003",
+    N.VW_E_LEVEL: "CFG_004",
+}
+
+
+def _raise_for_status(ctx: N.Context, st: int):
+    """Map a vw_status back onto the exception class the reference throws."""
+    if st == N.VW_OK:
+        return
+    msg = ctx.last_error()
+    code = _STATUS_TO_CODE.get(st)
+    if st in (N.VW_E_NONFINITE, N.VW_E_EMPTY):
+        raise InvalidSignalException(msg, code)
+    if st in (N.VW_E_LEVEL, N.VW_E_BOUNDARY, N.VW_E_TOO_LARGE):
+        raise InvalidArgumentException(msg, code)
+    if st == N.VW_E_NULL:
+        raise TypeError(msg)  # NullPointerException
+    if st == N.VW_E_NOT_POSITIVE:
+        raise ValueError(msg)  # IllegalArgumentException
+    if st == N.VW_E_LENGTH_MISMATCH:
+        raise IndexError(msg)  # ArrayIndexOutOfBoundsException in the reference
+    raise N.NativeLibraryError("libvwgpu status %d: %s" % (st, msg))
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _vp(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _taps(t) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(t, dtype=np.float64))
+
+
+def _require_signal(signal, name="signal") -> np.ndarray:
+    if signal is None:
+        raise TypeError("%s cannot be null" % name)
+    return np.ascontiguousarray(np.asarray(signal, dtype=np.float64))
+
+
+def _as_wavelet(w) -> Wavelet:
+    if w is None:
+        raise TypeError("wavelet cannot be null")
+    return get_wavelet(w) if isinstance(w, str) else w
+
+
+# ---------------------------------------------------------------------------
+# result containers
+# ---------------------------------------------------------------------------
+
+class MODWTResult:
+    """modwt/MODWTResult.java:24 + MODWTResultImpl.java:31-63 (finite check, defensive copies)."""
+
+    def __init__(self, approximationCoeffs, detailCoeffs, _validated=False):
+        if approximationCoeffs is None:
+            raise TypeError("approximationCoeffs cannot be null")
+        if detailCoeffs is None:
+            raise TypeError("detailCoeffs cannot be null")
+        a = np.array(approximationCoeffs, dtype=np.float64)
+        d = np.array(detailCoeffs, dtype=np.float64)
+        if a.shape != d.shape:
+            raise ValueError("Approximation and detail coefficients must have the same length.")
+        if a.size == 0:
+            raise ValueError("Coefficient arrays cannot be empty")
+        if not _validated:
+            for arr, nm in ((a, "approximationCoeffs"), (d, "detailCoeffs")):
+                bad = np.flatnonzero(~np.isfinite(arr))
+                if bad.size:
+                    raise InvalidSignalException("%s contains a non-finite value at index %d" % (nm, bad[0]), "VAL_003")
+        self._a, self._d = a, d
+
+    @staticmethod
+    def create(approximationCoeffs, detailCoeffs):
+        return MODWTResult(approximationCoeffs, detailCoeffs)
+
+    def approximationCoeffs(self):
+        return self._a.copy()
+
+    def detailCoeffs(self):
+        return self._d.copy()
+
+    def getSignalLength(self):
+        return int(self._a.size)
+
+    def isValid(self):
+        return bool(np.isfinite(self._a).all() and np.isfinite(self._d).all())
+
+
+class MultiLevelMODWTResult:
+    """Immutable J-level result (modwt/MultiLevelMODWTResultImpl.java:9), backed by one
+    contiguous [J+1][N] block ordered d_1..d_J, a_J."""
+
+    _mutable = False
+
+    def __init__(self, block: np.ndarray):
+        assert block.ndim == 2
+        self._block = block
+        self._levels = block.shape[0] - 1
+        self._n = block.shape[1]
+
+    def getLevels(self):
+        return self._levels
+
+    def getSignalLength(self):
+        return self._n
+
+    def _validate_level(self, level):
+        if level < 1 or level > self._levels:
+            raise ValueError("Level must be between 1 and %d, got: %d" % (self._levels, level))
+
+    def getDetailCoeffsAtLevel(self, level):
+        self._validate_level(level)
+        return self._block[level - 1].copy()
+
+    def getApproximationCoeffs(self):
+        return self._block[self._levels].copy()
+
+    @staticmethod
+    def _energy(c):
+        # sequential sum of squares, like the reference's computeEnergy loops
+        e = 0.0
+        for v in c.tolist():
+            e += v * v
+        return e
+
+    def getDetailEnergyAtLevel(self, level):
+        self._validate_level(level)
+        return self._energy(self._block[level - 1])
+
+    def getApproximationEnergy(self):
+        return self._energy(self._block[self._levels])
+
+    def getTotalEnergy(self):
+        total = self.getApproximationEnergy()
+        for level in range(1, self._levels + 1):
+            total += self.getDetailEnergyAtLevel(level)
+        return total
+
+    def getRelativeEnergyDistribution(self):
+        # immutable impl order: [approx, d1..dJ] (modwt/MultiLevelMODWTResultImpl.java:131-136)
+        total = self.getTotalEnergy()
+        dist = np.zeros(self._levels + 1)
+        if total > 0:
+            dist[0] = self.getApproximationEnergy() / total
+            for level in range(1, self._levels + 1):
+                dist[level] = self.getDetailEnergyAtLevel(level) / total
+        return dist
+
+    def copy(self):
+        return type(self)(self._block.copy())
+
+    def isValid(self):
+        return bool(np.isfinite(self._block).all())
+
+    def block(self) -> np.ndarray:
+        """The [J+1][N] coefficient block (d_1..d_J, a_J); a view, not a copy."""
+        return self._block
+
+
+class MutableMultiLevelMODWTResult(MultiLevelMODWTResult):
+    """modwt/MutableMultiLevelMODWTResultImpl.java:16"""
+
+    _mutable = True
+
+    def getMutableDetailCoeffs(self, level):
+        self._validate_level(level)
+        return self._block[level - 1]
+
+    def getMutableApproximationCoeffs(self):
+        return self._block[self._levels]
+
+    def _validate_coeffs(self, coeffs, name):
+        if coeffs is None:
+            raise TypeError("%s cannot be null" % name)
+        c = np.asarray(coeffs, dtype=np.float64)
+        if c.shape != (self._n,):
+            raise ValueError("%s length %d does not match signal length %d" % (name, c.size, self._n))
+        return c
+
+    def setDetailCoeffs(self, level, coeffs):
+        self._validate_level(level)
+        self._block[level - 1] = self._validate_coeffs(coeffs, "detail coefficients at level %d" % level)
+
+    def setApproximationCoeffs(self, coeffs):
+        self._block[self._levels] = self._validate_coeffs(coeffs, "approximation coefficients")
+
+    def clearCaches(self):
+        pass  # energies are not cached here
+
+    def applyThreshold(self, level, threshold, soft, ctx: Optional[N.Context] = None):
+        """modwt/MutableMultiLevelMODWTResult.java:83-114; level 0 = approximation."""
+        if level == 0:
+            row = self._block[self._levels]
+        else:
+            self._validate_level(level)
+            row = self._block[level - 1]
+        if threshold < 0:
+            # the reference's loop with a negative threshold: soft shrinks away from zero
+            # by |thr|, hard keeps everything; mirrored on the host because the C ABI
+            # (like WaveletOperations) rejects negative thresholds
+            if soft:
+                row[:] = np.where(np.abs(row) > threshold, np.sign(row) * (np.abs(row) - threshold), 0.0)
+            return
+        ctx = ctx or N.default_context()
+        out = np.empty_like(row)
+        st = ctx.lib.vw_threshold(ctx.handle, _vp(np.ascontiguousarray(row)), row.size, float(threshold),
+                                  1 if soft else 0, _vp(out))
+        _raise_for_status(ctx, st)
+        row[:] = out
+
+    def getRelativeEnergyDistribution(self):
+        # mutable impl order: [d1..dJ, approx] (modwt/MutableMultiLevelMODWTResultImpl.java:203-207)
+        total = self.getTotalEnergy()
+        dist = np.zeros(self._levels + 1)
+        if total > 0:
+            for level in range(1, self._levels + 1):
+                dist[level - 1] = self.getDetailEnergyAtLevel(level) / total
+            dist[self._levels] = self.getApproximationEnergy() / total
+        return dist
+
+    def toImmutable(self):
+        return MultiLevelMODWTResult(self._block.copy())
+
+
+# ---------------------------------------------------------------------------
+# WaveletOperations facade
+# ---------------------------------------------------------------------------
+
+class WaveletOperations:
+    """WaveletOperations.java:12: the static operator facade, now one downcall per batch."""
+
+    @staticmethod
+    def _convolve(signal, filt, output, boundary, level=1, ctx=None):
+        ctx = ctx or N.default_context()
+        s = _require_signal(signal)
+        f = _taps(filt)
+        x = s.reshape(1, -1) if s.ndim == 1 else s
+        out = np.empty_like(x)
+        st = ctx.lib.vw_modwt_convolve_batch(ctx.handle, _vp(x), x.shape[0], x.shape[1], _dp(f), f.size, level,
+                                             int(boundary), _vp(out))
+        _raise_for_status(ctx, st)
+        out = out.reshape(s.shape)
+        if output is not None:
+            output[...] = out
+            return output
+        return out
+
+    @staticmethod
+    def circularConvolveMODWT(signal, filt, output=None, ctx=None):
+        return WaveletOperations._convolve(signal, filt, output, BoundaryMode.PERIODIC, 1, ctx)
+
+    @staticmethod
+    def zeroPaddingConvolveMODWT(signal, filt, output=None, ctx=None):
+        return WaveletOperations._convolve(signal, filt, output, BoundaryMode.ZERO_PADDING, 1, ctx)
+
+    @staticmethod
+    def symmetricConvolveMODWT(signal, filt, output=None, ctx=None):
+        return WaveletOperations._convolve(signal, filt, output, BoundaryMode.SYMMETRIC, 1, ctx)
+
+    @staticmethod
+    def circularConvolveMODWTLevel(signal, filt, output=None, level=1, ctx=None):
+        """internal/ScalarOps.java:743-789"""
+        return WaveletOperations._convolve(signal, filt, output, BoundaryMode.PERIODIC, level, ctx)
+
+    @staticmethod
+    def _threshold(coefficients, threshold, soft, ctx=None):
+        if coefficients is None:
+            raise ValueError("Coefficients array cannot be null")
+        if threshold < 0:
+            raise ValueError("Threshold must be non-negative")
+        ctx = ctx or N.default_context()
+        c = np.ascontiguousarray(np.asarray(coefficients, dtype=np.float64))
+        out = np.empty_like(c)
+        st = ctx.lib.vw_threshold(ctx.handle, _vp(c), c.size, float(threshold), 1 if soft else 0, _vp(out))
+        _raise_for_status(ctx, st)
+        return out
+
+    @staticmethod
+    def softThreshold(coefficients, threshold, ctx=None):
+        return WaveletOperations._threshold(coefficients, threshold, True, ctx)
+
+    @staticmethod
+    def hardThreshold(coefficients, threshold, ctx=None):
+        return WaveletOperations._threshold(coefficients, threshold, False, ctx)
+
+    @staticmethod
+    def getPerformanceInfo(ctx=None):
+        ctx = ctx or N.default_context()
+        return ctx.performance_info()
+
+
+# ---------------------------------------------------------------------------
+# MODWTTransform (single level)
+# ---------------------------------------------------------------------------
+
+class MODWTTransform:
+    """modwt/MODWTTransform.java:69"""
+
+    def __init__(self, wavelet, boundaryMode, ctx: Optional[N.Context] = None):
+        self.wavelet = _as_wavelet(wavelet)
+        if boundaryMode is None:
+            raise TypeError("boundaryMode cannot be null")
+        try:
+            self.boundaryMode = BoundaryMode(boundaryMode)
+        except ValueError:
+            raise InvalidArgumentException(
+                "MODWT only supports PERIODIC, ZERO_PADDING, and SYMMETRIC boundary modes", "CFG_003")
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    def getWavelet(self):
+        return self.wavelet
+
+    def getBoundaryMode(self):
+        return self.boundaryMode
+
+    def getPerformanceInfo(self):
+        return self.ctx.performance_info()
+
+    # -- raw batch calls over contiguous blocks --------------------------------
+    def forward_block(self, x: np.ndarray, check_finite: bool) -> np.ndarray:
+        """x [B][N] -> coeffs [B][2][N] (detail, approximation)."""
+        ctx = self.ctx
+        b, n = x.shape
+        h, g = _taps(self.wavelet.dec_lo), _taps(self.wavelet.dec_hi)
+        out = np.empty((b, 2, n))
+        bad = C.c_int64(-1)
+        flags = N.VW_FLAG_SINGLE_LEVEL | (N.VW_FLAG_CHECK_FINITE if check_finite else 0)
+        st = ctx.lib.vw_modwt_forward_batch(ctx.handle, _vp(x), b, n, 1, _dp(h), h.size, _dp(g), g.size,
+                                            int(self.boundaryMode), flags, _vp(out), C.byref(bad))
+        _raise_for_status(ctx, st)
+        return out
+
+    def inverse_block(self, coeffs: np.ndarray, check_finite: bool, batch_variant: bool) -> np.ndarray:
+        ctx = self.ctx
+        b, two, n = coeffs.shape
+        hr, gr = _taps(self.wavelet.rec_lo), _taps(self.wavelet.rec_hi)
+        out = np.empty((b, n))
+        bad = C.c_int64(-1)
+        flags = N.VW_FLAG_SINGLE_LEVEL | (N.VW_FLAG_CHECK_FINITE if check_finite else 0) | (
+            N.VW_FLAG_SYMMETRIC_BATCH_VARIANT if batch_variant else 0)
+        st = ctx.lib.vw_modwt_inverse_batch(ctx.handle, _vp(coeffs), b, n, 1, _dp(hr), hr.size, _dp(gr), gr.size,
+                                            int(self.boundaryMode), flags, _vp(out), C.byref(bad))
+        _raise_for_status(ctx, st)
+        return out
+
+    # -- reference API -----------------------------------------------------------
+    def forward(self, signal) -> MODWTResult:
+        x = _require_signal(signal)
+        if x.size == 0:
+            raise InvalidSignalException("Signal cannot be empty", "VAL_006")
+        c = self.forward_block(x.reshape(1, -1), check_finite=True)
+        return MODWTResult(c[0, 1], c[0, 0], _validated=True)
+
+    def inverse(self, modwtResult: MODWTResult):
+        if modwtResult is None:
+            raise TypeError("modwtResult cannot be null")
+        if not modwtResult.isValid():
+            raise InvalidSignalException("MODWTResult contains invalid coefficients", "VAL_003")
+        c = np.stack([modwtResult._d, modwtResult._a])[None]
+        return self.inverse_block(np.ascontiguousarray(c), check_finite=False, batch_variant=False)[0]
+
+    def forwardBatch(self, signals) -> List[MODWTResult]:
+        if signals is None:
+            raise TypeError("signals array cannot be null")
+        if len(signals) == 0:
+            return []
+        rows = [_require_signal(s) for s in signals]
+        first = rows[0].size
+        same = all(r.size == first for r in rows)
+        if same and len(rows) >= 4 and first >= 64:
+            # forwardBatchOptimized (modwt/MODWTTransform.java:537-587): no input validation; a
+            # non-finite coefficient surfaces when the per-signal result objects are built
+            c = self.forward_block(np.ascontiguousarray(np.stack(rows)), check_finite=False)
+            return [MODWTResult(c[i, 1], c[i, 0]) for i in range(len(rows))]
+        return [self.forward(r) for r in rows]
+
+    def inverseBatch(self, results: Sequence[MODWTResult]):
+        if results is None:
+            raise TypeError("results array cannot be null")
+        if len(results) == 0:
+            return []
+        first = results[0].getSignalLength()
+        same = all(r.getSignalLength() == first for r in results)
+        if same and len(results) >= 4 and first >= 64:
+            c = np.ascontiguousarray(np.stack([np.stack([r._d, r._a]) for r in results]))
+            out = self.inverse_block(c, check_finite=False, batch_variant=True)
+            return [out[i] for i in range(len(results))]
+        return [self.inverse(r) for r in results]
+
+
+# ---------------------------------------------------------------------------
+# MultiLevelMODWTTransform
+# ---------------------------------------------------------------------------
+
+class MultiLevelMODWTTransform:
+    """modwt/MultiLevelMODWTTransform.java:66"""
+
+    MAX_DECOMPOSITION_LEVELS = 10
+
+    def __init__(self, wavelet, boundaryMode, ctx: Optional[N.Context] = None):
+        self.wavelet = _as_wavelet(wavelet)
+        if boundaryMode is None:
+            raise TypeError("boundaryMode cannot be null")
+        self.singleLevelTransform = MODWTTransform(self.wavelet, boundaryMode, ctx)
+        self.boundaryMode = self.singleLevelTransform.boundaryMode
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    def getWavelet(self):
+        return self.wavelet
+
+    def getBoundaryMode(self):
+        return self.boundaryMode
+
+    @staticmethod
+    def getMaxDecompositionLevels():
+        return MultiLevelMODWTTransform.MAX_DECOMPOSITION_LEVELS
+
+    def getMaximumLevels(self, signalLength):
+        lib = N.load()
+        return min(int(lib.vw_max_levels(int(signalLength), len(self.wavelet.dec_lo))),
+                   self.MAX_DECOMPOSITION_LEVELS)
+
+    # -- batch surface (new: modelled on MODWTTransform.forwardBatch) ----------
+    def decompose_block(self, x: np.ndarray, levels: int, check_finite: bool = True) -> np.ndarray:
+        """x [B][N] -> coeffs [B][J+1][N]."""
+        ctx = self.ctx
+        b, n = x.shape
+        h, g = _taps(self.wavelet.dec_lo), _taps(self.wavelet.dec_hi)
+        out = np.empty((b, levels + 1 if levels >= 0 else 1, n))
+        bad = C.c_int64(-1)
+        flags = N.VW_FLAG_CHECK_FINITE if check_finite else 0
+        st = ctx.lib.vw_modwt_forward_batch(ctx.handle, _vp(x), b, n, int(levels), _dp(h), h.size, _dp(g), g.size,
+                                            int(self.boundaryMode), flags, _vp(out), C.byref(bad))
+        if st == N.VW_E_LEVEL and check_finite and b > 0 and n > 0:
+            # decompose() validates finiteness before the level count
+            # (modwt/MultiLevelMODWTTransform.java:216-244)
+            st2 = ctx.lib.vw_first_non_finite(ctx.handle, _vp(x), x.size, C.byref(bad))
+            if st2 == N.VW_E_NONFINITE:
+                _raise_for_status(ctx, st2)
+            raise InvalidArgumentException("Invalid number of decomposition levels", "CFG_004")
+        _raise_for_status(ctx, st)
+        return out
+
+    def reconstruct_block(self, coeffs: np.ndarray, band_mask: Optional[int] = None) -> np.ndarray:
+        ctx = self.ctx
+        b, jp1, n = coeffs.shape
+        hr, gr = _taps(self.wavelet.rec_lo), _taps(self.wavelet.rec_hi)
+        out = np.empty((b, n))
+        if band_mask is None:
+            bad = C.c_int64(-1)
+            st = ctx.lib.vw_modwt_inverse_batch(ctx.handle, _vp(coeffs), b, n, jp1 - 1, _dp(hr), hr.size, _dp(gr),
+                                                gr.size, int(self.boundaryMode), 0, _vp(out), C.byref(bad))
+        else:
+            st = ctx.lib.vw_modwt_inverse_bands_batch(ctx.handle, _vp(coeffs), b, n, jp1 - 1, _dp(hr), hr.size, _dp(gr),
+                                                      gr.size, int(self.boundaryMode), int(band_mask), _vp(out))
+        _raise_for_status(ctx, st)
+        return out
+
+    def decomposeBatch(self, signals, levels: Optional[int] = None) -> List[MultiLevelMODWTResult]:
+        x = np.ascontiguousarray(np.asarray(signals, dtype=np.float64))
+        if x.ndim != 2:
+            raise ValueError("decomposeBatch needs equal-length signals [B][N]")
+        if levels is None:
+            levels = self.getMaximumLevels(x.shape[1])
+        c = self.decompose_block(x, levels)
+        return [MultiLevelMODWTResult(c[i]) for i in range(x.shape[0])]
+
+    def reconstructBatch(self, results: Sequence[MultiLevelMODWTResult]):
+        if len(results) == 0:
+            return []
+        c = np.ascontiguousarray(np.stack([r.block() for r in results]))
+        out = self.reconstruct_block(c)
+        return [out[i] for i in range(len(results))]
+
+    # -- reference API -----------------------------------------------------------
+    def _decompose(self, signal, levels, cls):
+        x = _require_signal(signal)
+        if levels is None:
+            levels = self.getMaximumLevels(x.size)
+        if x.size == 0:
+            raise InvalidSignalException("Signal cannot be empty for multi-level MODWT", "VAL_006")
+        c = self.decompose_block(x.reshape(1, -1), int(levels))
+        return cls(c[0])
+
+    def decompose(self, signal, levels: Optional[int] = None) -> MultiLevelMODWTResult:
+        return self._decompose(signal, levels, MultiLevelMODWTResult)
+
+    def decomposeMutable(self, signal, levels: Optional[int] = None) -> MutableMultiLevelMODWTResult:
+        return self._decompose(signal, levels, MutableMultiLevelMODWTResult)
+
+    def reconstruct(self, result: MultiLevelMODWTResult):
+        if result is None:
+            raise TypeError("result cannot be null")
+        return self.reconstruct_block(np.ascontiguousarray(result.block())[None])[0]
+
+    def reconstructFromLevel(self, result, startLevel):
+        """modwt/MultiLevelMODWTTransform.java:385-410: details finer than startLevel are zeros."""
+        if result is None:
+            raise TypeError("result cannot be null")
+        J = result.getLevels()
+        if startLevel < 1 or startLevel > J:
+            raise InvalidArgumentException("Invalid start level: %d. Must be between 1 and %d" % (startLevel, J))
+        mask = (1 << J)  # approximation
+        for level in range(startLevel, J + 1):
+            mask |= 1 << (level - 1)
+        return self.reconstruct_block(np.ascontiguousarray(result.block())[None], mask)[0]
+
+    def reconstructLevels(self, result, minLevel, maxLevel):
+        """modwt/MultiLevelMODWTTransform.java:420-468: band-pass; the approximation takes part
+        only when the top level is inside the range."""
+        if result is None:
+            raise TypeError("result cannot be null")
+        J = result.getLevels()
+        if minLevel < 1 or maxLevel > J or minLevel > maxLevel:
+            raise InvalidArgumentException("Invalid level range for partial reconstruction", "CFG_004")
+        mask = 0
+        for level in range(minLevel, maxLevel + 1):
+            mask |= 1 << (level - 1)
+        if J <= maxLevel:
+            mask |= 1 << J
+        return self.reconstruct_block(np.ascontiguousarray(result.block())[None], mask)[0]
+
+
+# ---------------------------------------------------------------------------
+# VectorWaveSwtAdapter
+# ---------------------------------------------------------------------------
+
+class VectorWaveSwtAdapter:
+    """swt/VectorWaveSwtAdapter.java:61"""
+
+    PARALLEL_THRESHOLD = 4096
+
+    def __init__(self, wavelet, boundaryMode=BoundaryMode.PERIODIC, ctx: Optional[N.Context] = None):
+        if wavelet is None:
+            raise TypeError("Wavelet cannot be null")
+        if boundaryMode is None:
+            raise TypeError("Boundary mode cannot be null")
+        self.wavelet = _as_wavelet(wavelet)
+        self.modwtTransform = MultiLevelMODWTTransform(self.wavelet, boundaryMode, ctx)
+        self.boundaryMode = self.modwtTransform.boundaryMode
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    def getWavelet(self):
+        return self.wavelet
+
+    def getBoundaryMode(self):
+        return self.boundaryMode
+
+    def forward(self, signal, levels: Optional[int] = None) -> MutableMultiLevelMODWTResult:
+        return self.modwtTransform.decomposeMutable(signal, levels)
+
+    def inverse(self, result: MutableMultiLevelMODWTResult):
+        return self.modwtTransform.reconstruct(result)
+
+    def applyThreshold(self, result, level, threshold, soft):
+        if result is None:
+            raise TypeError("Result cannot be null")
+        result.applyThreshold(level, threshold, soft, self.ctx)
+
+    def universalThreshold(self, result) -> float:
+        """The threshold applyUniversalThreshold derives (swt/VectorWaveSwtAdapter.java:255-264)."""
+        ctx = self.ctx
+        blk = np.ascontiguousarray(result.block())[None]
+        n = result.getSignalLength()
+        thr = np.empty(1)
+        st = ctx.lib.vw_swt_universal_threshold_batch(ctx.handle, _vp(blk), 1, n, result.getLevels(),
+                                                      math.sqrt(2 * math.log(n)), _vp(thr))
+        _raise_for_status(ctx, st)
+        return float(thr[0])
+
+    def applyUniversalThreshold(self, result, soft):
+        if result is None:
+            raise TypeError("Result cannot be null")
+        thr = self.universalThreshold(result)
+        for level in range(1, result.getLevels() + 1):
+            self.applyThreshold(result, level, thr, soft)
+
+    def denoise_block(self, x: np.ndarray, levels: int, threshold: float = -1.0, soft: bool = True,
+                      return_thresholds: bool = False):
+        """x [B][N] -> denoised [B][N] in one downcall (new batch surface)."""
+        ctx = self.ctx
+        b, n = x.shape
+        w = self.wavelet
+        h, g, hr, gr = _taps(w.dec_lo), _taps(w.dec_hi), _taps(w.rec_lo), _taps(w.rec_hi)
+        out = np.empty((b, n))
+        thr = np.empty(b)
+        s2 = math.sqrt(2 * math.log(n)) if n > 0 else 0.0
+        st = ctx.lib.vw_swt_denoise_batch(ctx.handle, _vp(x), b, n, int(levels), _dp(h), h.size, _dp(g), g.size,
+                                          _dp(hr), hr.size, _dp(gr), gr.size, int(self.boundaryMode),
+                                          float(threshold), s2, 1 if soft else 0, _vp(out), _vp(thr))
+        _raise_for_status(ctx, st)
+        return (out, thr) if return_thresholds else out
+
+    def denoise(self, signal, levels, threshold: float = -1, soft: bool = True):
+        x = _require_signal(signal)
+        if x.size == 0:
+            raise InvalidSignalException("Signal cannot be empty for multi-level MODWT", "VAL_006")
+        # forward() -> decomposeMutable() validates finiteness first
+        bad = C.c_int64(-1)
+        _raise_for_status(self.ctx, self.ctx.lib.vw_first_non_finite(self.ctx.handle, _vp(x), x.size, C.byref(bad)))
+        return self.denoise_block(x.reshape(1, -1), levels, threshold, soft)[0]
+
+    def denoiseBatch(self, signals, levels, threshold: float = -1, soft: bool = True):
+        x = np.ascontiguousarray(np.asarray(signals, dtype=np.float64))
+        return self.denoise_block(x, levels, threshold, soft)
+
+    def extractLevel(self, signal, levels, targetLevel):
+        """swt/VectorWaveSwtAdapter.java:326-348: keep one band, reconstruct."""
+        result = self.forward(signal, levels)
+        mask = (1 << levels) if targetLevel == 0 else (1 << (targetLevel - 1) if 1 <= targetLevel <= levels else 0)
+        return self.modwtTransform.reconstruct_block(np.ascontiguousarray(result.block())[None], mask)[0]
+
+    def cleanup(self):
+        pass
+
+    def getCacheStatistics(self):
+        return {"filterCacheSize": 0, "parallelExecutorActive": False, "parallelThreshold": self.PARALLEL_THRESHOLD}

@@ -1,0 +1,1153 @@
+// vw_capi.hip -- C ABI (include/vwgpu.h) over the gfx950 kernels.
+//
+// Host side of the engine: argument validation with the reference's error
+// codes, 1/sqrt(2) tap scaling, level grouping + halo planning for the fused
+// tile kernels, kernel-instance dispatch, staging for the host-pointer entry
+// points.  No CPU compute path exists here: without a HIP device every entry
+// point that would compute fails with VW_E_NO_DEVICE.
+#include "vw_kernels.hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/vwgpu.h"
+
+using namespace vw;
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct vw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    char info[512] = {0};
+    std::recursive_mutex mu;  // serialises use of the context-owned buffers below
+    DevBuf ws;          // ping-pong plane [B][N] for multi-group / generic plans
+    DevBuf stage_in;    // host-pointer entry points: device copy of the input
+    DevBuf stage_out;   // ... and of the output
+    DevBuf denoise_ws;  // coefficient block for vw_swt_denoise_batch(_dev) when the caller passes none
+    DevBuf cell;        // 8-byte first_bad cell for host-pointer entry points
+    int lds_limit = 65536;
+};
+
+static int set_err(vw_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx != nullptr) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define VW_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_err((ctx), e_ == hipErrorOutOfMemory ? VW_E_NOMEM : VW_E_HIP, "%s: %s", #call, \
+                           hipGetErrorString(e_));                                               \
+    } while (0)
+
+static int ensure(vw_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p != nullptr) return VW_OK;
+    if (b.p != nullptr) {
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VW_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    if (bytes == 0) bytes = 8;
+    VW_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return VW_OK;
+}
+
+extern "C" int32_t vw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int32_t vw_init(int32_t device, vw_ctx** out_ctx) {
+    if (out_ctx == nullptr) return VW_E_NULL;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VW_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return VW_E_NO_DEVICE;
+    vw_ctx* ctx = new (std::nothrow) vw_ctx();
+    if (ctx == nullptr) return VW_E_NOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return VW_E_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->lds_limit = static_cast<int>(prop.sharedMemPerBlock);
+        if (strncmp(prop.gcnArchName, "gfx950", 6) == 0 && ctx->lds_limit < 160 * 1024) ctx->lds_limit = 160 * 1024;
+        snprintf(ctx->info, sizeof(ctx->info),
+                 "HIP device %d: %s (%s), %d CUs, %.0f GiB HBM, %d KiB LDS/workgroup; fp64 MODWT kernels: "
+                 "LDS-tiled fused levels, no FMA contraction",
+                 device, prop.name, prop.gcnArchName, prop.multiProcessorCount,
+                 static_cast<double>(prop.totalGlobalMem) / (1024.0 * 1024.0 * 1024.0), ctx->lds_limit / 1024);
+    } else {
+        snprintf(ctx->info, sizeof(ctx->info), "HIP device %d", device);
+    }
+    strcpy(ctx->err, "no error");
+    *out_ctx = ctx;
+    return VW_OK;
+}
+
+extern "C" int32_t vw_destroy(vw_ctx* ctx) {
+    if (ctx == nullptr) return VW_E_NULL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->ws, &ctx->stage_in, &ctx->stage_out, &ctx->denoise_ws, &ctx->cell};
+    for (DevBuf* b : bufs)
+        if (b->p != nullptr) (void)hipFree(b->p);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VW_OK;
+}
+
+extern "C" const char* vw_last_error(const vw_ctx* ctx) { return ctx != nullptr ? ctx->err : "null context"; }
+extern "C" const char* vw_performance_info(const vw_ctx* ctx) { return ctx != nullptr ? ctx->info : "null context"; }
+
+extern "C" int32_t vw_synchronize(vw_ctx* ctx) {
+    if (ctx == nullptr) return VW_E_NULL;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+// MultiLevelMODWTTransform.calculateMaxLevels (modwt/MultiLevelMODWTTransform.java:477-523)
+extern "C" int32_t vw_max_levels(int64_t n, int32_t filter_len) {
+    if (n <= filter_len) return 0;
+    int max_level = 1;
+    const int64_t lm1 = filter_len - 1;
+    while (max_level < 10) {
+        if (max_level - 1 >= 31) break;
+        const int64_t scaled = lm1 * (static_cast<int64_t>(1) << (max_level - 1)) + 1;
+        if (scaled > n) break;
+        ++max_level;
+    }
+    return max_level - 1;
+}
+
+// ---------------------------------------------------------------------------
+// planning
+// ---------------------------------------------------------------------------
+
+static constexpr int kHaloMaxChunks = 10;  // largest HPT instantiated
+
+struct TileCfg {
+    int ppt, hpt;
+};
+
+// Instantiated (PPT, HPT) pairs.  Keep in sync with the dispatch switch below.
+static const TileCfg kCfgs[] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {8, 2}, {8, 4}, {8, 10}};
+
+static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileCfg* out) {
+    int hpt_need = static_cast<int>((halo + kChunk - 1) / kChunk);
+    if (hpt_need < 1) hpt_need = 1;
+    int64_t row_chunks = (n + kChunk - 1) / kChunk;  // chunks that cover one row
+    if (row_chunks < 1) row_chunks = 1;
+    const int ncfg = static_cast<int>(sizeof(kCfgs) / sizeof(kCfgs[0]));
+    // smallest instantiated halo that covers the need and fits LDS
+    int hpt = 0;
+    for (int i = 0; i < ncfg; ++i) {
+        const TileCfg& c = kCfgs[i];
+        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * (inverse ? 2 : 1);
+        if (c.hpt < hpt_need || lds > static_cast<size_t>(lds_limit)) continue;
+        if (hpt == 0 || c.hpt < hpt) hpt = c.hpt;
+    }
+    if (hpt == 0) return false;
+    // with that halo: the largest tile that does not exceed the row, else the smallest tile
+    int best = -1;
+    for (int i = 0; i < ncfg; ++i) {
+        const TileCfg& c = kCfgs[i];
+        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * (inverse ? 2 : 1);
+        if (c.hpt != hpt || lds > static_cast<size_t>(lds_limit)) continue;
+        if (best < 0) {
+            best = i;
+            continue;
+        }
+        const TileCfg& b = kCfgs[best];
+        const bool c_in = c.ppt <= row_chunks, b_in = b.ppt <= row_chunks;
+        if ((c_in && (!b_in || c.ppt > b.ppt)) || (!c_in && !b_in && c.ppt < b.ppt)) best = i;
+    }
+    *out = kCfgs[best];
+    return true;
+}
+
+// Left halo a fused forward group lev0..lev1 needs, and per-level start positions.
+static int64_t fwd_halo(int lev0, int lev1, int lh, int lg, int64_t* hn /*[kMaxLevels+1]*/) {
+    int64_t need = 0;  // Hn_{lev1} = 0
+    if (hn != nullptr) hn[lev1] = 0;
+    for (int j = lev1; j >= lev0; --j) {
+        const int64_t s = static_cast<int64_t>(1) << (j - 1);
+        const int64_t a = need + static_cast<int64_t>(lh - 1) * s;
+        const int64_t b = static_cast<int64_t>(lg - 1) * s;
+        need = a > b ? a : b;
+        if (hn != nullptr && j - 1 >= 0) hn[j - 1] = need;
+    }
+    return need;
+}
+
+// Right halo a fused inverse group lev1..lev0 needs.
+static int64_t inv_halo(int lev0, int lev1, int lh) {
+    int64_t e = 0;
+    for (int j = lev0; j <= lev1; ++j) e += static_cast<int64_t>(lh - 1) * (static_cast<int64_t>(1) << (j - 1));
+    return e;
+}
+
+struct Step {
+    int lev0, lev1;
+    bool fused;
+    TileCfg cfg;
+};
+
+static void scale_taps(const double* src, int len, double* dst) {
+    // MODWTTransform.java:133-142: scale = 1.0 / Math.sqrt(2.0); tap * scale
+    const double scale = 1.0 / sqrt(2.0);
+    for (int i = 0; i < len; ++i) dst[i] = src[i] * scale;
+    for (int i = len; i < kMaxTaps + 2; ++i) dst[i] = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// kernel-instance dispatch
+// ---------------------------------------------------------------------------
+
+template <typename K, typename A>
+static hipError_t launch_tile(K kernel, const A& args, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), lds, stream, args);
+    return hipGetLastError();
+}
+
+#define VW_FWD_CASE(P, H)                                                                              \
+    if (cfg.ppt == P && cfg.hpt == H) {                                                                \
+        if (mode == kPeriodic)                                                                         \
+            return vec2 ? launch_tile(k_fwd_fused<P, H, kPeriodic, true>, a, nblocks, lds, stream)     \
+                        : launch_tile(k_fwd_fused<P, H, kPeriodic, false>, a, nblocks, lds, stream);   \
+        return vec2 ? launch_tile(k_fwd_fused<P, H, kZeroPad, true>, a, nblocks, lds, stream)          \
+                    : launch_tile(k_fwd_fused<P, H, kZeroPad, false>, a, nblocks, lds, stream);        \
+    }
+
+static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, int64_t nblocks,
+                             hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8;
+    VW_FWD_CASE(1, 1)
+    VW_FWD_CASE(2, 1)
+    VW_FWD_CASE(4, 1)
+    VW_FWD_CASE(8, 1)
+    VW_FWD_CASE(4, 2)
+    VW_FWD_CASE(8, 2)
+    VW_FWD_CASE(8, 4)
+    VW_FWD_CASE(8, 10)
+    return hipErrorInvalidValue;
+}
+
+#define VW_INV_CASE(P, H)                                                                              \
+    if (cfg.ppt == P && cfg.hpt == H) {                                                                \
+        if (mode == kPeriodic)                                                                         \
+            return vec2 ? launch_tile(k_inv_fused<P, H, kPeriodic, true>, a, nblocks, lds, stream)     \
+                        : launch_tile(k_inv_fused<P, H, kPeriodic, false>, a, nblocks, lds, stream);   \
+        return vec2 ? launch_tile(k_inv_fused<P, H, kZeroPad, true>, a, nblocks, lds, stream)          \
+                    : launch_tile(k_inv_fused<P, H, kZeroPad, false>, a, nblocks, lds, stream);        \
+    }
+
+static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, int64_t nblocks,
+                             hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8 * 2;
+    VW_INV_CASE(1, 1)
+    VW_INV_CASE(2, 1)
+    VW_INV_CASE(4, 1)
+    VW_INV_CASE(8, 1)
+    VW_INV_CASE(4, 2)
+    VW_INV_CASE(8, 2)
+    VW_INV_CASE(8, 4)
+    VW_INV_CASE(8, 10)
+    return hipErrorInvalidValue;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------
+// common argument checks
+// ---------------------------------------------------------------------------
+
+static int check_common(vw_ctx* ctx, int64_t b, int64_t n, int levels, int l0, int l1, int boundary) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative batch size %lld", static_cast<long long>(b));
+    if (n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative signal length %lld", static_cast<long long>(n));
+    if (boundary != VW_BOUNDARY_PERIODIC && boundary != VW_BOUNDARY_ZERO_PADDING &&
+        boundary != VW_BOUNDARY_SYMMETRIC)
+        return set_err(ctx, VW_E_BOUNDARY, "MODWT only supports PERIODIC, ZERO_PADDING, and SYMMETRIC boundary modes");
+    if (l0 < 1 || l1 < 1 || l0 > kMaxTaps || l1 > kMaxTaps)
+        return set_err(ctx, VW_E_LENGTH_MISMATCH, "filter lengths %d/%d outside [1, %d]", l0, l1, kMaxTaps);
+    if (n == 0 && b > 0) return set_err(ctx, VW_E_EMPTY, "Signal cannot be empty");
+    if (levels - 1 >= 31) return set_err(ctx, VW_E_TOO_LARGE, "Decomposition level would cause integer overflow");
+    if (n > 0 && b > 0 && (b > INT64_MAX / n / (levels + 2))) return set_err(ctx, VW_E_TOO_LARGE, "batch too large");
+    return VW_OK;
+}
+
+static int check_levels(vw_ctx* ctx, int64_t n, int levels, int lh, uint32_t flags) {
+    if (flags & VW_FLAG_SINGLE_LEVEL) {
+        if (levels != 1) return set_err(ctx, VW_E_LEVEL, "VW_FLAG_SINGLE_LEVEL requires levels == 1");
+        return VW_OK;
+    }
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of decomposition levels %d", levels);
+    if (flags & VW_FLAG_NO_LEVEL_CHECK) return VW_OK;
+    const int maxl = vw_max_levels(n, lh);
+    if (levels > maxl)
+        return set_err(ctx, VW_E_LEVEL, "Invalid number of decomposition levels %d (maximum %d for N=%lld, L=%d)", levels,
+                       maxl, static_cast<long long>(n), lh);
+    return VW_OK;
+}
+
+// number of taps of an L-tap filter whose dilated position l*s stays below n
+// (MultiLevelMODWTTransform's truncation of a zero-stuffed filter to n entries)
+static int truncated_taps(int len, int64_t s, int64_t n) {
+    const int64_t keep = (n - 1) / s + 1;
+    return keep < len ? static_cast<int>(keep) : len;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+
+static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int levels, const double* h, int lh,
+                       const double* g, int lg, int boundary, uint32_t flags, double* coeffs,
+                       unsigned long long* first_bad_cell, hipStream_t stream) {
+    Taps taps;
+    scale_taps(h, lh, taps.lo);
+    scale_taps(g, lg, taps.hi);
+    const bool single = (flags & VW_FLAG_SINGLE_LEVEL) != 0;
+    const int64_t band = n;
+    const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
+    double* aslot = coeffs + static_cast<int64_t>(levels) * n;  // row 0 of the a_J band
+
+    // truncation (multi-level API only) and boundary decide fused vs generic
+    bool generic_all = (boundary == VW_BOUNDARY_SYMMETRIC);
+    if (!single) {
+        for (int j = 1; j <= levels; ++j) {
+            const int64_t s = static_cast<int64_t>(1) << (j - 1);
+            if (truncated_taps(lh, s, n) != lh || truncated_taps(lg, s, n) != lg) generic_all = true;
+        }
+    }
+
+    // ---- plan ----------------------------------------------------------------
+    std::vector<Step> steps;
+    {
+        int j = 1;
+        while (j <= levels) {
+            Step st;
+            st.lev0 = j;
+            st.lev1 = j;
+            st.fused = false;
+            st.cfg = TileCfg{0, 0};
+            if (!generic_all) {
+                int hi = j;
+                TileCfg cfg;
+                if (pick_cfg(n, fwd_halo(j, j, lh, lg, nullptr), ctx->lds_limit, false, &cfg)) {
+                    st.fused = true;
+                    st.cfg = cfg;
+                    while (hi + 1 <= levels) {
+                        TileCfg c2;
+                        const int64_t hneed = fwd_halo(j, hi + 1, lh, lg, nullptr);
+                        if (hneed > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
+                        if (!pick_cfg(n, hneed, ctx->lds_limit, false, &c2)) break;
+                        st.cfg = c2;
+                        ++hi;
+                    }
+                    st.lev1 = hi;
+                }
+            }
+            steps.push_back(st);
+            j = st.lev1 + 1;
+        }
+    }
+    const int nsteps = static_cast<int>(steps.size());
+    if (nsteps > 1) {
+        const int rc = ensure(ctx, ctx->ws, static_cast<size_t>(b) * n * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* wsp = static_cast<double*>(ctx->ws.p);
+
+    // ---- run -----------------------------------------------------------------
+    const double* in = x;
+    int64_t in_stride = n;
+    bool first = true;
+    for (int i = 0; i < nsteps; ++i) {
+        const Step& st = steps[i];
+        // ping-pong so that the last step lands in the a_J band
+        const bool to_slot = ((nsteps - 1 - i) % 2) == 0;
+        double* vout = to_slot ? aslot : wsp;
+        const int64_t vstride = to_slot ? rowc : n;
+        if (st.fused) {
+            FwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = in;
+            a.in_stride = in_stride;
+            a.wout = coeffs;
+            a.w_row_stride = rowc;
+            a.w_band_stride = band;
+            a.vout = vout;
+            a.v_stride = vstride;
+            a.n = n;
+            a.nrows = b;
+            const int T = st.cfg.ppt * kChunk;
+            a.ntiles = static_cast<int32_t>((n + T - 1) / T);
+            a.lev0 = st.lev0;
+            a.lev1 = st.lev1;
+            a.lh = lh;
+            a.lg = lg;
+            int64_t hn[kMaxLevels + 2] = {0};
+            fwd_halo(st.lev0, st.lev1, lh, lg, hn);
+            const int64_t halo = static_cast<int64_t>(st.cfg.hpt) * kChunk;
+            for (int j = st.lev0; j <= st.lev1; ++j) {
+                int64_t ps = halo - hn[j];
+                if (ps < 0) ps = 0;
+                a.pstart[j] = static_cast<int32_t>(ps & ~static_cast<int64_t>(1));
+            }
+            a.first_bad = first ? first_bad_cell : nullptr;
+            a.taps = taps;
+            const bool vec2 = (n % 2 == 0) && (in_stride % 2 == 0) && (vstride % 2 == 0) && aligned16(in) &&
+                              aligned16(coeffs) && aligned16(vout);
+            const int64_t nblocks = b * a.ntiles;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, nblocks, stream);
+            if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
+        } else {
+            if (first && first_bad_cell != nullptr) {
+                hipLaunchKernelGGL(k_first_non_finite, dim3(1024), dim3(kThreads), 0, stream, x, b * n, first_bad_cell);
+            }
+            LevelArgs a;
+            memset(&a, 0, sizeof(a));
+            const int j = st.lev0;
+            a.in = in;
+            a.in_stride = in_stride;
+            a.out_lo = vout;
+            a.out_lo_stride = vstride;
+            a.out_hi = coeffs + static_cast<int64_t>(j - 1) * band;
+            a.out_hi_stride = rowc;
+            a.n = n;
+            a.nrows = b;
+            a.stride = static_cast<int64_t>(1) << (j - 1);
+            a.llo = single ? lh : truncated_taps(lh, a.stride, n);
+            a.lhi = single ? lg : truncated_taps(lg, a.stride, n);
+            a.taps = taps;
+            const int64_t per_row = (n + kThreads - 1) / kThreads;
+            const int64_t nblocks = per_row * b;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            if (boundary == VW_BOUNDARY_PERIODIC)
+                hipLaunchKernelGGL(k_level_fwd<kPeriodic>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            else if (boundary == VW_BOUNDARY_ZERO_PADDING)
+                hipLaunchKernelGGL(k_level_fwd<kZeroPad>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            else
+                hipLaunchKernelGGL(k_level_fwd<kSymmetric>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward level kernel launch: %s", hipGetErrorString(e));
+        }
+        in = vout;
+        in_stride = vstride;
+        first = false;
+    }
+    return VW_OK;
+}
+
+static int forward_checks(vw_ctx* ctx, const void* x, int64_t b, int64_t n, int levels, const double* h, int lh,
+                          const double* g, int lg, int boundary, uint32_t flags, const void* coeffs) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (h == nullptr || g == nullptr) return set_err(ctx, VW_E_NULL, "filter cannot be null");
+    int rc = check_common(ctx, b, n, levels, lh, lg, boundary);
+    if (rc != VW_OK) return rc;
+    if (b > 0 && (x == nullptr || coeffs == nullptr)) return set_err(ctx, VW_E_NULL, "signal cannot be null");
+    return check_levels(ctx, n, levels, lh, flags);
+}
+
+extern "C" int32_t vw_modwt_forward_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
+                                              const double* h, int32_t lh, const double* g, int32_t lg,
+                                              int32_t boundary, uint32_t flags, double* coeffs_dev,
+                                              int64_t* first_bad_dev, void* stream) {
+    int rc = forward_checks(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, flags, coeffs_dev);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    unsigned long long* cell = nullptr;
+    if ((flags & VW_FLAG_CHECK_FINITE) && first_bad_dev != nullptr) {
+        VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
+        cell = reinterpret_cast<unsigned long long*>(first_bad_dev);
+    }
+    return forward_dev(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, flags, coeffs_dev, cell, s);
+}
+
+// Rows per staging pass of the host-pointer entry points.
+static int64_t stage_rows(int64_t b, int64_t n, int bands_total) {
+    const int64_t budget = static_cast<int64_t>(4) << 30;  // ~4 GiB of device staging per pass
+    int64_t rows = budget / (n * 8 * bands_total);
+    if (rows < 1) rows = 1;
+    return rows < b ? rows : b;
+}
+
+extern "C" int32_t vw_modwt_forward_batch(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int32_t levels,
+                                          const double* h, int32_t lh, const double* g, int32_t lg, int32_t boundary,
+                                          uint32_t flags, double* coeffs, int64_t* first_bad) {
+    if (first_bad != nullptr) *first_bad = -1;
+    int rc = forward_checks(ctx, x, b, n, levels, h, lh, g, lg, boundary, flags, coeffs);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = stage_rows(b, n, levels + 2);
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(rows) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(rows) * (levels + 1) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->cell, 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* dc = static_cast<double*>(ctx->stage_out.p);
+    int64_t* cell = static_cast<int64_t*>(ctx->cell.p);
+    const bool chk = (flags & VW_FLAG_CHECK_FINITE) != 0;
+    for (int64_t r0 = 0; r0 < b; r0 += rows) {
+        const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
+        VW_HIP(ctx, hipMemcpyAsync(dx, x + r0 * n, static_cast<size_t>(nr) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = vw_modwt_forward_batch_dev(ctx, dx, nr, n, levels, h, lh, g, lg, boundary, flags | VW_FLAG_NO_LEVEL_CHECK,
+                                        dc, chk ? cell : nullptr, nullptr);
+        if (rc != VW_OK) return rc;
+        VW_HIP(ctx, hipMemcpyAsync(coeffs + r0 * (levels + 1) * n, dc, static_cast<size_t>(nr) * (levels + 1) * n * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        int64_t bad = -1;
+        if (chk) VW_HIP(ctx, hipMemcpyAsync(&bad, cell, 8, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (chk && bad >= 0) {
+            if (first_bad != nullptr) *first_bad = r0 * n + bad;
+            return set_err(ctx, VW_E_NONFINITE, "signal contains a non-finite value at index %lld",
+                           static_cast<long long>(r0 * n + bad));
+        }
+    }
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// inverse
+// ---------------------------------------------------------------------------
+
+static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels, const double* hr, int lhr,
+                       const double* gr, int lgr, int boundary, uint32_t flags, uint32_t band_mask, int thr_mode,
+                       const double* thr_rows, double* xout, unsigned long long* first_bad_cell, hipStream_t stream) {
+    Taps taps;
+    scale_taps(hr, lhr, taps.lo);
+    scale_taps(gr, lgr, taps.hi);
+    const bool single = (flags & VW_FLAG_SINGLE_LEVEL) != 0;
+    const int64_t band = n;
+    const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
+    const double* aslot = coeffs + static_cast<int64_t>(levels) * n;
+
+    bool generic_all = (boundary == VW_BOUNDARY_SYMMETRIC);
+    if (!single) {
+        for (int j = 1; j <= levels; ++j) {
+            const int64_t s = static_cast<int64_t>(1) << (j - 1);
+            if (truncated_taps(lhr, s, n) != lhr || truncated_taps(lgr, s, n) != lgr) generic_all = true;
+        }
+    }
+    if (generic_all && thr_mode != 0) return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
+
+    std::vector<Step> steps;
+    {
+        int j = levels;
+        while (j >= 1) {
+            Step st;
+            st.lev0 = j;
+            st.lev1 = j;
+            st.fused = false;
+            st.cfg = TileCfg{0, 0};
+            if (!generic_all) {
+                TileCfg cfg;
+                if (pick_cfg(n, inv_halo(j, j, lhr), ctx->lds_limit, true, &cfg)) {
+                    st.fused = true;
+                    st.cfg = cfg;
+                    int lo = j;
+                    while (lo - 1 >= 1) {
+                        TileCfg c2;
+                        const int64_t hneed = inv_halo(lo - 1, j, lhr);
+                        if (hneed > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
+                        if (!pick_cfg(n, hneed, ctx->lds_limit, true, &c2)) break;
+                        st.cfg = c2;
+                        --lo;
+                    }
+                    st.lev0 = lo;
+                }
+            }
+            steps.push_back(st);
+            j = st.lev0 - 1;
+        }
+    }
+    const int nsteps = static_cast<int>(steps.size());
+    if (nsteps > 1) {
+        const int rc = ensure(ctx, ctx->ws, static_cast<size_t>(b) * n * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* wsp = static_cast<double*>(ctx->ws.p);
+
+    const double* rin = aslot;
+    int64_t rin_stride = rowc;
+    bool use_rin = ((band_mask >> levels) & 1u) != 0;
+    bool first = true;
+    for (int i = 0; i < nsteps; ++i) {
+        const Step& st = steps[i];
+        const bool to_out = ((nsteps - 1 - i) % 2) == 0;
+        double* rout = to_out ? xout : wsp;
+        const int64_t rstride = n;
+        if (st.fused) {
+            InvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rin = rin;
+            a.rin_stride = rin_stride;
+            a.win = coeffs;
+            a.w_row_stride = rowc;
+            a.w_band_stride = band;
+            a.rout = rout;
+            a.rout_stride = rstride;
+            a.n = n;
+            a.nrows = b;
+            const int T = st.cfg.ppt * kChunk;
+            const int M = (st.cfg.ppt + st.cfg.hpt) * kChunk;
+            a.ntiles = static_cast<int32_t>((n + T - 1) / T);
+            a.lev0 = st.lev0;
+            a.lev1 = st.lev1;
+            a.lh = lhr;
+            int64_t e = 0;  // E_{lev0-1} = 0
+            a.pend[st.lev0 - 1] = T;
+            for (int j = st.lev0; j <= st.lev1; ++j) {
+                e += static_cast<int64_t>(lhr - 1) * (static_cast<int64_t>(1) << (j - 1));
+                int64_t pe = T + ((e + 1) & ~static_cast<int64_t>(1));
+                if (pe > M) pe = M;
+                a.pend[j] = static_cast<int32_t>(pe);
+            }
+            a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
+            a.thr_mode = thr_mode;
+            a.thr = thr_rows;
+            a.first_bad = first_bad_cell;
+            a.taps = taps;
+            const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
+            const int64_t nblocks = b * a.ntiles;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            hipError_t er = launch_inv(a, st.cfg, boundary, vec2, nblocks, stream);
+            if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));
+        } else {
+            if (first && first_bad_cell != nullptr)
+                hipLaunchKernelGGL(k_first_non_finite, dim3(1024), dim3(kThreads), 0, stream, coeffs, b * rowc, first_bad_cell);
+            LevelArgs a;
+            memset(&a, 0, sizeof(a));
+            const int j = st.lev0;
+            a.in = rin;
+            a.in_stride = rin_stride;
+            a.din = coeffs + static_cast<int64_t>(j - 1) * band;
+            a.din_stride = rowc;
+            a.out_lo = rout;
+            a.out_lo_stride = rstride;
+            a.n = n;
+            a.nrows = b;
+            a.stride = static_cast<int64_t>(1) << (j - 1);
+            a.llo = single ? lhr : truncated_taps(lhr, a.stride, n);
+            a.lhi = single ? lgr : truncated_taps(lgr, a.stride, n);
+            a.variant = single ? ((flags & VW_FLAG_SYMMETRIC_BATCH_VARIANT) ? 2 : 1) : 0;
+            a.use_in = use_rin ? 1 : 0;
+            a.use_din = ((band_mask >> (j - 1)) & 1u) ? 1 : 0;
+            a.taps = taps;
+            const int64_t per_row = (n + kThreads - 1) / kThreads;
+            const int64_t nblocks = per_row * b;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            if (boundary == VW_BOUNDARY_PERIODIC)
+                hipLaunchKernelGGL(k_level_inv<kPeriodic>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            else if (boundary == VW_BOUNDARY_ZERO_PADDING)
+                hipLaunchKernelGGL(k_level_inv<kZeroPad>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            else
+                hipLaunchKernelGGL(k_level_inv<kSymmetric>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, stream, a);
+            hipError_t er = hipGetLastError();
+            if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse level kernel launch: %s", hipGetErrorString(er));
+        }
+        rin = rout;
+        rin_stride = rstride;
+        use_rin = true;
+        first = false;
+    }
+    return VW_OK;
+}
+
+static int inverse_checks(vw_ctx* ctx, const void* coeffs, int64_t b, int64_t n, int levels, const double* hr, int lhr,
+                          const double* gr, int lgr, int boundary, uint32_t flags, const void* x) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (hr == nullptr || gr == nullptr) return set_err(ctx, VW_E_NULL, "filter cannot be null");
+    int rc = check_common(ctx, b, n, levels, lhr, lgr, boundary);
+    if (rc != VW_OK) return rc;
+    if (b > 0 && (x == nullptr || coeffs == nullptr)) return set_err(ctx, VW_E_NULL, "coefficients cannot be null");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if ((flags & VW_FLAG_SINGLE_LEVEL) && levels != 1) return set_err(ctx, VW_E_LEVEL, "VW_FLAG_SINGLE_LEVEL requires levels == 1");
+    // The reference loops l < len(lowPassRecon) and indexes highPassRecon[l].
+    const bool pair_loop = boundary != VW_BOUNDARY_SYMMETRIC || (flags & VW_FLAG_SINGLE_LEVEL);
+    if (pair_loop && lgr < lhr)
+        return set_err(ctx, VW_E_LENGTH_MISMATCH,
+                       "high-pass reconstruction filter (%d taps) shorter than low-pass (%d): the reference indexes out of bounds here",
+                       lgr, lhr);
+    return VW_OK;
+}
+
+extern "C" int32_t vw_modwt_inverse_bands_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n,
+                                                    int32_t levels, const double* hr, int32_t lhr, const double* gr,
+                                                    int32_t lgr, int32_t boundary, uint32_t band_mask, double* x_dev,
+                                                    void* stream) {
+    int rc = inverse_checks(ctx, coeffs_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, x_dev);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    return inverse_dev(ctx, coeffs_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, band_mask, 0, nullptr, x_dev,
+                       nullptr, s);
+}
+
+extern "C" int32_t vw_modwt_inverse_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n,
+                                              int32_t levels, const double* hr, int32_t lhr, const double* gr,
+                                              int32_t lgr, int32_t boundary, uint32_t flags, double* x_dev,
+                                              int64_t* first_bad_dev, void* stream) {
+    int rc = inverse_checks(ctx, coeffs_dev, b, n, levels, hr, lhr, gr, lgr, boundary, flags, x_dev);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    unsigned long long* cell = nullptr;
+    if ((flags & VW_FLAG_CHECK_FINITE) && first_bad_dev != nullptr) {
+        VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
+        cell = reinterpret_cast<unsigned long long*>(first_bad_dev);
+    }
+    return inverse_dev(ctx, coeffs_dev, b, n, levels, hr, lhr, gr, lgr, boundary, flags, 0xffffffffu, 0, nullptr, x_dev,
+                       cell, s);
+}
+
+static int inverse_host(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int32_t levels, const double* hr,
+                        int32_t lhr, const double* gr, int32_t lgr, int32_t boundary, uint32_t flags,
+                        uint32_t band_mask, bool use_mask, double* x, int64_t* first_bad) {
+    if (first_bad != nullptr) *first_bad = -1;
+    int rc = inverse_checks(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, flags, x);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = stage_rows(b, n, levels + 2);
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(rows) * (levels + 1) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(rows) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->cell, 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* dc = static_cast<double*>(ctx->stage_in.p);
+    double* dx = static_cast<double*>(ctx->stage_out.p);
+    int64_t* cell = static_cast<int64_t*>(ctx->cell.p);
+    const bool chk = (flags & VW_FLAG_CHECK_FINITE) != 0;
+    for (int64_t r0 = 0; r0 < b; r0 += rows) {
+        const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
+        VW_HIP(ctx, hipMemcpyAsync(dc, coeffs + r0 * (levels + 1) * n, static_cast<size_t>(nr) * (levels + 1) * n * 8,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        if (use_mask)
+            rc = vw_modwt_inverse_bands_batch_dev(ctx, dc, nr, n, levels, hr, lhr, gr, lgr, boundary, band_mask, dx, nullptr);
+        else
+            rc = vw_modwt_inverse_batch_dev(ctx, dc, nr, n, levels, hr, lhr, gr, lgr, boundary, flags, dx,
+                                            chk ? cell : nullptr, nullptr);
+        if (rc != VW_OK) return rc;
+        VW_HIP(ctx, hipMemcpyAsync(x + r0 * n, dx, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        int64_t bad = -1;
+        if (chk && !use_mask) VW_HIP(ctx, hipMemcpyAsync(&bad, cell, 8, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (chk && !use_mask && bad >= 0) {
+            if (first_bad != nullptr) *first_bad = r0 * (levels + 1) * n + bad;
+            return set_err(ctx, VW_E_NONFINITE, "MODWTResult contains invalid coefficients (index %lld)",
+                           static_cast<long long>(r0 * (levels + 1) * n + bad));
+        }
+    }
+    return VW_OK;
+}
+
+extern "C" int32_t vw_modwt_inverse_batch(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int32_t levels,
+                                          const double* hr, int32_t lhr, const double* gr, int32_t lgr,
+                                          int32_t boundary, uint32_t flags, double* x, int64_t* first_bad) {
+    return inverse_host(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, flags, 0xffffffffu, false, x, first_bad);
+}
+
+extern "C" int32_t vw_modwt_inverse_bands_batch(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n,
+                                                int32_t levels, const double* hr, int32_t lhr, const double* gr,
+                                                int32_t lgr, int32_t boundary, uint32_t band_mask, double* x) {
+    return inverse_host(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, 0, band_mask, true, x, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// thresholds / universal threshold / denoise
+// ---------------------------------------------------------------------------
+
+extern "C" int32_t vw_threshold_dev(vw_ctx* ctx, const double* in_dev, int64_t count, double threshold, int32_t soft,
+                                    double* out_dev, void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
+    if (count > 0 && (in_dev == nullptr || out_dev == nullptr)) return set_err(ctx, VW_E_NULL, "Coefficients array cannot be null");
+    if (threshold < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold must be non-negative");
+    if (count == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    int64_t blocks = (count + kThreads - 1) / kThreads;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_threshold, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, in_dev, out_dev, count,
+                       threshold, soft ? 1 : 2);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_threshold(vw_ctx* ctx, const double* in, int64_t count, double threshold, int32_t soft,
+                                double* out) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
+    if (count > 0 && (in == nullptr || out == nullptr)) return set_err(ctx, VW_E_NULL, "Coefficients array cannot be null");
+    if (threshold < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold must be non-negative");
+    if (count == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        int rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(count) * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* d = static_cast<double*>(ctx->stage_in.p);
+    VW_HIP(ctx, hipMemcpyAsync(d, in, static_cast<size_t>(count) * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = vw_threshold_dev(ctx, d, count, threshold, soft, d, nullptr);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(out, d, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+static double host_sqrt_2_ln_n(int64_t n) { return sqrt(2 * log(static_cast<double>(n))); }
+
+static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels,
+                                   double sqrt_2_ln_n, double* thr, hipStream_t s) {
+    MedianArgs a;
+    a.d1 = coeffs;
+    a.row_stride = static_cast<int64_t>(levels + 1) * n;
+    a.n = n;
+    a.nrows = b;
+    a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
+    a.thr_out = thr;
+    // rows up to 4096 samples are copied to LDS (32 KiB) so that the nine passes never leave the CU
+    a.lds_cap = 4096;
+    const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
+    if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    hipLaunchKernelGGL(k_universal_threshold, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_swt_universal_threshold_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n,
+                                                        int32_t levels, double sqrt_2_ln_n, double* thresholds_dev,
+                                                        void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (b > 0 && (coeffs_dev == nullptr || thresholds_dev == nullptr)) return set_err(ctx, VW_E_NULL, "Result cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Signal cannot be empty");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    return universal_threshold_dev(ctx, coeffs_dev, b, n, levels, sqrt_2_ln_n, thresholds_dev, s);
+}
+
+extern "C" int32_t vw_swt_universal_threshold_batch(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n,
+                                                    int32_t levels, double sqrt_2_ln_n, double* thresholds) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (b > 0 && (coeffs == nullptr || thresholds == nullptr)) return set_err(ctx, VW_E_NULL, "Result cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Signal cannot be empty");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    // only band d_1 of each row is needed on the device
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        int rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(b) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(b) * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* d = static_cast<double*>(ctx->stage_in.p);
+    double* t = static_cast<double*>(ctx->stage_out.p);
+    VW_HIP(ctx, hipMemcpy2DAsync(d, static_cast<size_t>(n) * 8, coeffs, static_cast<size_t>(levels + 1) * n * 8,
+                                 static_cast<size_t>(n) * 8, static_cast<size_t>(b), hipMemcpyHostToDevice, ctx->stream));
+    MedianArgs a;
+    a.d1 = d;
+    a.row_stride = n;
+    a.n = n;
+    a.nrows = b;
+    a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
+    a.thr_out = t;
+    a.lds_cap = 4096;
+    const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
+    hipLaunchKernelGGL(k_universal_threshold, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, ctx->stream, a);
+    VW_HIP(ctx, hipGetLastError());
+    VW_HIP(ctx, hipMemcpyAsync(thresholds, t, static_cast<size_t>(b) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+extern "C" size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels) {
+    if (b <= 0 || n <= 0 || levels < 1) return 0;
+    // coefficient block + per-row thresholds (rounded up to 256 B)
+    const size_t coeffs = static_cast<size_t>(b) * static_cast<size_t>(levels + 1) * static_cast<size_t>(n) * 8;
+    const size_t thr = (static_cast<size_t>(b) * 8 + 255) & ~static_cast<size_t>(255);
+    return coeffs + thr;
+}
+
+__global__ void __launch_bounds__(kThreads) k_fill(double* p, int64_t count, double v) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+// thresholds every detail band of every row in place (generic-path denoise)
+__global__ void __launch_bounds__(kThreads) k_threshold_rows(double* coeffs, int64_t n, int levels,
+                                                             const double* __restrict__ thr, int mode) {
+    const int64_t row = blockIdx.y;
+    const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
+    const int64_t cnt = static_cast<int64_t>(levels) * n;
+    double* p = coeffs + row * rowc;
+    const double t = thr[row];
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < cnt;
+         i += static_cast<int64_t>(gridDim.x) * kThreads)
+        p[i] = apply_thr(p[i], t, mode);
+}
+
+extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
+                                            const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
+                                            int32_t lhr, const double* gr, int32_t lgr, int32_t boundary,
+                                            double threshold, double sqrt_2_ln_n, int32_t soft, double* y_dev,
+                                            double* thresholds_out_dev, void* workspace_dev, size_t workspace_bytes,
+                                            void* stream) {
+    int rc = forward_checks(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, 0, y_dev);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, y_dev);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    const size_t need = vw_swt_denoise_workspace_bytes(b, n, levels);
+    char* wsb;
+    if (workspace_dev != nullptr) {
+        if (workspace_bytes < need) return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        wsb = static_cast<char*>(workspace_dev);
+    } else {
+        rc = ensure(ctx, ctx->denoise_ws, need);
+        if (rc != VW_OK) return rc;
+        wsb = static_cast<char*>(ctx->denoise_ws.p);
+    }
+    double* coeffs = reinterpret_cast<double*>(wsb);
+    double* thr = reinterpret_cast<double*>(wsb + static_cast<size_t>(b) * (levels + 1) * n * 8);
+
+    rc = forward_dev(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, 0, coeffs, nullptr, s);
+    if (rc != VW_OK) return rc;
+    if (threshold < 0) {
+        rc = universal_threshold_dev(ctx, coeffs, b, n, levels, sqrt_2_ln_n, thr, s);
+        if (rc != VW_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(k_fill, dim3(static_cast<unsigned>((b + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, thr, b,
+                           threshold);
+        VW_HIP(ctx, hipGetLastError());
+    }
+    if (thresholds_out_dev != nullptr)
+        VW_HIP(ctx, hipMemcpyAsync(thresholds_out_dev, thr, static_cast<size_t>(b) * 8, hipMemcpyDeviceToDevice, s));
+    const int mode = soft ? 1 : 2;
+    // fused inverse thresholds the detail bands as they are loaded; the generic
+    // path (SYMMETRIC, truncated filters) thresholds the block in place first
+    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
+    for (int j = 1; j <= levels; ++j) {
+        const int64_t st = static_cast<int64_t>(1) << (j - 1);
+        if (truncated_taps(lhr, st, n) != lhr || truncated_taps(lgr, st, n) != lgr) generic = true;
+    }
+    if (generic) {
+        const int64_t cnt = static_cast<int64_t>(levels) * n;
+        int64_t bx = (cnt + kThreads - 1) / kThreads;
+        if (bx > 1024) bx = 1024;
+        for (int64_t r0 = 0; r0 < b; r0 += 65535) {
+            const int64_t nr = (b - r0) < 65535 ? (b - r0) : 65535;
+            hipLaunchKernelGGL(k_threshold_rows, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nr)), dim3(kThreads), 0, s,
+                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0, mode);
+        }
+        VW_HIP(ctx, hipGetLastError());
+        return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, 0, 0xffffffffu, 0, nullptr, y_dev, nullptr, s);
+    }
+    return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, 0, 0xffffffffu, mode, thr, y_dev, nullptr, s);
+}
+
+extern "C" int32_t vw_swt_denoise_batch(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int32_t levels,
+                                        const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
+                                        int32_t lhr, const double* gr, int32_t lgr, int32_t boundary, double threshold,
+                                        double sqrt_2_ln_n, int32_t soft, double* y, double* thresholds_out) {
+    int rc = forward_checks(ctx, x, b, n, levels, h, lh, g, lg, boundary, 0, y);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x, b, n, levels, hr, lhr, gr, lgr, boundary, 0, y);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = stage_rows(b, n, levels + 3);
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(rows) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(rows) * n * 8 + static_cast<size_t>(rows) * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* dy = static_cast<double*>(ctx->stage_out.p);
+    double* dthr = dy + rows * n;
+    for (int64_t r0 = 0; r0 < b; r0 += rows) {
+        const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
+        VW_HIP(ctx, hipMemcpyAsync(dx, x + r0 * n, static_cast<size_t>(nr) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = vw_swt_denoise_batch_dev(ctx, dx, nr, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold,
+                                      sqrt_2_ln_n, soft, dy, thresholds_out != nullptr ? dthr : nullptr, nullptr, 0, nullptr);
+        if (rc != VW_OK) return rc;
+        VW_HIP(ctx, hipMemcpyAsync(y + r0 * n, dy, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (thresholds_out != nullptr)
+            VW_HIP(ctx, hipMemcpyAsync(thresholds_out + r0, dthr, static_cast<size_t>(nr) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// raw convolution + validation
+// ---------------------------------------------------------------------------
+
+extern "C" int32_t vw_modwt_convolve_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n,
+                                               const double* filter, int32_t filter_len, int32_t level,
+                                               int32_t boundary, double* out_dev, void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (filter == nullptr) return set_err(ctx, VW_E_NULL, "filter cannot be null");
+    if (level < 1) return set_err(ctx, VW_E_LEVEL, "level must be >= 1");
+    int rc = check_common(ctx, b, n, level, filter_len, filter_len, boundary);
+    if (rc != VW_OK) return rc;
+    if (b > 0 && (x_dev == nullptr || out_dev == nullptr)) return set_err(ctx, VW_E_NULL, "signal cannot be null");
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    LevelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = x_dev;
+    a.in_stride = n;
+    a.out_lo = out_dev;
+    a.out_lo_stride = n;
+    a.out_hi = nullptr;
+    a.n = n;
+    a.nrows = b;
+    a.stride = static_cast<int64_t>(1) << (level - 1);
+    a.llo = filter_len;
+    a.lhi = 0;
+    for (int i = 0; i < kMaxTaps + 2; ++i) {
+        a.taps.lo[i] = i < filter_len ? filter[i] : 0.0;
+        a.taps.hi[i] = 0.0;
+    }
+    const int64_t per_row = (n + kThreads - 1) / kThreads;
+    const int64_t nblocks = per_row * b;
+    if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    if (boundary == VW_BOUNDARY_PERIODIC)
+        hipLaunchKernelGGL(k_level_fwd<kPeriodic>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
+    else if (boundary == VW_BOUNDARY_ZERO_PADDING)
+        hipLaunchKernelGGL(k_level_fwd<kZeroPad>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_level_fwd<kSymmetric>, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_modwt_convolve_batch(vw_ctx* ctx, const double* x, int64_t b, int64_t n, const double* filter,
+                                           int32_t filter_len, int32_t level, int32_t boundary, double* out) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (filter == nullptr) return set_err(ctx, VW_E_NULL, "filter cannot be null");
+    if (level < 1) return set_err(ctx, VW_E_LEVEL, "level must be >= 1");
+    int rc = check_common(ctx, b, n, level, filter_len, filter_len, boundary);
+    if (rc != VW_OK) return rc;
+    if (b > 0 && (x == nullptr || out == nullptr)) return set_err(ctx, VW_E_NULL, "signal cannot be null");
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(b) * n * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(b) * n * 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* dy = static_cast<double*>(ctx->stage_out.p);
+    VW_HIP(ctx, hipMemcpyAsync(dx, x, static_cast<size_t>(b) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_modwt_convolve_batch_dev(ctx, dx, b, n, filter, filter_len, level, boundary, dy, nullptr);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(out, dy, static_cast<size_t>(b) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+extern "C" int32_t vw_first_non_finite_dev(vw_ctx* ctx, const double* x_dev, int64_t count, int64_t* first_bad_dev,
+                                           void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (first_bad_dev == nullptr) return set_err(ctx, VW_E_NULL, "first_bad cannot be null");
+    if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
+    if (count > 0 && x_dev == nullptr) return set_err(ctx, VW_E_NULL, "signal cannot be null");
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
+    if (count == 0) return VW_OK;
+    int64_t blocks = (count + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_first_non_finite, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, x_dev, count,
+                       reinterpret_cast<unsigned long long*>(first_bad_dev));
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_first_non_finite(vw_ctx* ctx, const double* x, int64_t count, int64_t* first_bad) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (first_bad == nullptr) return set_err(ctx, VW_E_NULL, "first_bad cannot be null");
+    *first_bad = -1;
+    if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
+    if (count == 0) return VW_OK;
+    if (x == nullptr) return set_err(ctx, VW_E_NULL, "signal cannot be null");
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    {
+        int rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(count) * 8);
+        if (rc == VW_OK) rc = ensure(ctx, ctx->cell, 8);
+        if (rc != VW_OK) return rc;
+    }
+    double* d = static_cast<double*>(ctx->stage_in.p);
+    int64_t* cell = static_cast<int64_t*>(ctx->cell.p);
+    VW_HIP(ctx, hipMemcpyAsync(d, x, static_cast<size_t>(count) * 8, hipMemcpyHostToDevice, ctx->stream));
+    int rc = vw_first_non_finite_dev(ctx, d, count, cell, nullptr);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(first_bad, cell, 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*first_bad >= 0) return set_err(ctx, VW_E_NONFINITE, "signal contains a non-finite value at index %lld", static_cast<long long>(*first_bad));
+    return VW_OK;
+}

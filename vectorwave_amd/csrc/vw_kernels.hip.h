@@ -1,0 +1,809 @@
+// vw_kernels.hip.h -- gfx950 device code of the MODWT / SWT engine.
+//
+// The transform is an a-trous stencil: at level j (stride s = 2^(j-1))
+//   V_j[t] = sum_l lo[l] * V_{j-1}[t - l*s]      W_j[t] = sum_l hi[l] * V_{j-1}[t - l*s]
+// and the inverse walks back with a look-ahead
+//   R_{j-1}[t] = sum_l ( lo~[l] * R_j[t + l*s] + hi~[l] * W_j[t + l*s] ).
+// It is HBM-bound fp64 work (no MFMA): every kernel here is built around
+// coalesced 16-byte-per-lane global accesses, an LDS-resident signal tile with a
+// halo sized for the dilated support, taps read through the scalar unit, and all
+// levels of a group fused per tile so intermediates never travel to HBM.
+//
+// Arithmetic contract (the reference's scalar Java path): every product and every
+// sum is rounded separately, taps are accumulated in ascending l starting from
+// +0.0.  FP contraction is therefore disabled for the whole translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace vw {
+
+constexpr int kThreads = 256;           // 4 wavefronts per workgroup
+constexpr int kChunk = 2 * kThreads;    // samples covered by one pass of the workgroup (a pair per lane)
+constexpr int kMaxTaps = 104;           // longest reference filter is coif17 (102 taps)
+constexpr int kMaxLevels = 12;          // reference cap is 9
+
+constexpr int kPeriodic = 0;
+constexpr int kZeroPad = 1;
+constexpr int kSymmetric = 2;
+
+// Filter pair, already multiplied by 1/sqrt(2) on the host.  Passed by value in
+// the kernel argument segment so the taps are fetched with scalar loads.  Two
+// spare slots let the tap loop prefetch one tap ahead without a bounds check.
+struct Taps {
+    double lo[kMaxTaps + 2];
+    double hi[kMaxTaps + 2];
+};
+
+struct FwdArgs {
+    const double* in;      // V_{lev0-1}: rows of length n
+    int64_t in_stride;     // elements between rows of `in`
+    double* wout;          // detail bands: row r, level j at wout + r*w_row_stride + (j-1)*w_band_stride
+    int64_t w_row_stride;
+    int64_t w_band_stride;
+    double* vout;          // V_{lev1}
+    int64_t v_stride;
+    int64_t n;
+    int64_t nrows;
+    int32_t ntiles;
+    int32_t lev0, lev1;    // levels computed by this launch (inclusive)
+    int32_t lh, lg;        // tap counts of lo / hi
+    int32_t pstart[kMaxLevels + 1];  // first buffer position at which V_j is computed (even)
+    unsigned long long* first_bad;   // nullptr = no finite check
+    Taps taps;
+};
+
+struct InvArgs {
+    const double* rin;     // R_{lev1}: rows of length n (a_J for the top group)
+    int64_t rin_stride;
+    const double* win;     // detail bands, addressed like FwdArgs::wout
+    int64_t w_row_stride;
+    int64_t w_band_stride;
+    double* rout;          // R_{lev0-1}
+    int64_t rout_stride;
+    int64_t n;
+    int64_t nrows;
+    int32_t ntiles;
+    int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
+    int32_t lh;            // loop bound (low-pass reconstruction length)
+    int32_t pend[kMaxLevels + 1];    // R_{j} is valid on buffer positions [0, pend[j]) (even)
+    uint32_t band_mask;    // bit (j-1): use W_j, else zeros; bit 31: use rin, else zeros
+    int32_t thr_mode;      // 0 none, 1 soft, 2 hard: applied to W_j as it is loaded
+    const double* thr;     // per-row threshold (thr_mode != 0)
+    unsigned long long* first_bad;
+    Taps taps;
+};
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+
+// Workgroups are dealt round-robin over the 8 XCDs, so ids b and b+8 share an
+// L2.  Remap so that each XCD walks a contiguous run of (row, tile) ids: adjacent
+// tiles of one row overlap in their halo and then hit in the same L2.  Bijective
+// for any grid size.
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblk) {
+    const int64_t q = nblk >> 3, r = nblk & 7;
+    const int64_t x = bid & 7, k = bid >> 3;
+    const int64_t base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
+
+__device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n) {
+    int64_t m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+// util/MathUtils.symmetricBoundaryExtension of the reference.
+__device__ __forceinline__ int64_t sym_reflect(int64_t idx, int64_t n) {
+    if (idx >= 0 && idx < n) return idx;
+    const int64_t period = 2 * n;
+    idx = ((idx % period) + period) % period;
+    if (idx >= n) idx = period - idx - 1;
+    return idx;
+}
+
+__device__ __forceinline__ bool finite_f64(double v) {
+    return (__double_as_longlong(v) & 0x7ff0000000000000LL) != 0x7ff0000000000000LL;
+}
+
+// MutableMultiLevelMODWTResult.applyThresholdToArray of the reference.
+// mode 1: soft  |c| > thr ? signum(c) * (|c| - thr) : 0.0
+// mode 2: hard  |c| <= thr ? 0.0 : c
+__device__ __forceinline__ double apply_thr(double c, double thr, int mode) {
+    const double a = fabs(c);
+    if (mode == 1) {
+        if (a > thr) {
+            const double m = a - thr;
+            // signum(c) * m with signum in {+1, -1, +-0}: a > thr >= 0 excludes zero unless thr < 0
+            return c > 0.0 ? m : (c < 0.0 ? -m : c * m);
+        }
+        return 0.0;
+    }
+    return (a <= thr) ? 0.0 : c;
+}
+
+// ---------------------------------------------------------------------------
+// fused forward: levels lev0..lev1 of one (row, tile) per workgroup
+// ---------------------------------------------------------------------------
+//
+// LDS buffer: M = (HPT + PPT) * 512 doubles, position p <-> sample t = t0 - HALO + p.
+// Each lane owns the aligned pair (p, p+1), p = chunk*512 + 2*lane, of every
+// chunk: PPT tile chunks (V and W computed) and HPT halo chunks (V only, and only
+// where the shrinking halo still needs it).  Results stay in registers across
+// the barrier and overwrite the buffer in place, so one buffer serves all levels.
+
+template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI>
+__device__ __forceinline__ void fwd_tap(const char* lds, int baseT, int baseH, int off, double flo,
+                                        double fhi, double (&av)[PPT][2], double (&aw)[PPT][2],
+                                        double (&ah)[HPT][2], double (&xp)[PPT], double (&xph)[HPT],
+                                        const bool (&hact)[HPT]) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        double x0, x1;
+        if (S1) {
+            x0 = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) - off);
+            x1 = xp[k];
+            xp[k] = x0;
+        } else {
+            const double2 x = *reinterpret_cast<const double2*>(lds + baseT + k * (kChunk * 8) - off);
+            x0 = x.x;
+            x1 = x.y;
+        }
+        if (DO_LO) {
+            av[k][0] = av[k][0] + x0 * flo;
+            av[k][1] = av[k][1] + x1 * flo;
+        }
+        if (DO_HI) {
+            aw[k][0] = aw[k][0] + x0 * fhi;
+            aw[k][1] = aw[k][1] + x1 * fhi;
+        }
+    }
+    if (DO_LO) {
+#pragma unroll
+        for (int c = 0; c < HPT; ++c) {
+            if (hact[c]) {
+                double x0, x1;
+                if (S1) {
+                    x0 = *reinterpret_cast<const double*>(lds + baseH + c * (kChunk * 8) - off);
+                    x1 = xph[c];
+                    xph[c] = x0;
+                } else {
+                    const double2 x =
+                        *reinterpret_cast<const double2*>(lds + baseH + c * (kChunk * 8) - off);
+                    x0 = x.x;
+                    x1 = x.y;
+                }
+                ah[c][0] = ah[c][0] + x0 * flo;
+                ah[c][1] = ah[c][1] + x1 * flo;
+            }
+        }
+    }
+}
+
+template <int PPT, int HPT, bool S1>
+__device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int s, int tid,
+                                          double (&av)[PPT][2], double (&aw)[PPT][2],
+                                          double (&ah)[HPT][2], const bool (&hact)[HPT]) {
+    constexpr int HALO = HPT * kChunk;
+    const int baseT = (HALO + 2 * tid) * 8;
+    const int baseH = (2 * tid) * 8;
+    double xp[PPT], xph[HPT];
+    if (S1) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            xp[k] = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) + 8);
+#pragma unroll
+        for (int c = 0; c < HPT; ++c)
+            xph[c] = hact[c] ? *reinterpret_cast<const double*>(lds + baseH + c * (kChunk * 8) + 8) : 0.0;
+    }
+    const int lh = a.lh, lg = a.lg;
+    const int lmin = lh < lg ? lh : lg;
+    const int sb = s * 8;
+    int off = 0;
+    int l = 0;
+    double flo = a.taps.lo[0], fhi = a.taps.hi[0];
+    for (; l < lmin; ++l) {
+        const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
+        fwd_tap<PPT, HPT, S1, true, true>(lds, baseT, baseH, off, flo, fhi, av, aw, ah, xp, xph, hact);
+        off += sb;
+        flo = flo_n;
+        fhi = fhi_n;
+    }
+    for (; l < lh; ++l) {  // low-pass longer than high-pass
+        const double flo_n = a.taps.lo[l + 1];
+        fwd_tap<PPT, HPT, S1, true, false>(lds, baseT, baseH, off, flo, 0.0, av, aw, ah, xp, xph, hact);
+        off += sb;
+        flo = flo_n;
+    }
+    for (; l < lg; ++l) {  // high-pass longer than low-pass
+        const double fhi_n = a.taps.hi[l + 1];
+        fwd_tap<PPT, HPT, S1, false, true>(lds, baseT, baseH, off, 0.0, fhi, av, aw, ah, xp, xph, hact);
+        off += sb;
+        fhi = fhi_n;
+    }
+}
+
+template <int PPT, int HPT, int MODE, bool VEC2>
+__global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
+    extern __shared__ double2 vw_smem[];
+    char* lds = reinterpret_cast<char*>(vw_smem);
+    double* buf = reinterpret_cast<double*>(vw_smem);
+    constexpr int HALO = HPT * kChunk;
+    constexpr int T = PPT * kChunk;
+    const int tid = threadIdx.x;
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int tile = static_cast<int>(id - row * a.ntiles);
+    const int64_t t0 = static_cast<int64_t>(tile) * T;
+    const int64_t n = a.n;
+    const double* __restrict__ inrow = a.in + row * a.in_stride;
+
+    // ---- stage V_{lev0-1}[t0-HALO, t0+T) into LDS --------------------------------
+    {
+        double2 v[HPT + PPT];
+#pragma unroll
+        for (int c = 0; c < HPT + PPT; ++c) {
+            const int p = c * kChunk + 2 * tid;
+            const int64_t t = t0 - HALO + p;
+            double2 x = make_double2(0.0, 0.0);
+            if (t >= 0) {
+                if (VEC2) {
+                    if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
+                } else {
+                    if (t < n) x.x = inrow[t];
+                    if (t + 1 < n) x.y = inrow[t + 1];
+                }
+            } else if (MODE == kPeriodic) {
+                if (VEC2) {
+                    x = *reinterpret_cast<const double2*>(inrow + mod_wrap(t, n));
+                } else {
+                    x.x = inrow[mod_wrap(t, n)];
+                    x.y = inrow[mod_wrap(t + 1, n)];
+                }
+            }
+            v[c] = x;
+        }
+        if (a.first_bad != nullptr) {
+#pragma unroll
+            for (int c = HPT; c < HPT + PPT; ++c) {
+                const int64_t t = t0 - HALO + c * kChunk + 2 * tid;
+                if (t < n && !finite_f64(v[c].x))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
+                if (t + 1 < n && !finite_f64(v[c].y))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HPT + PPT; ++c)
+            *reinterpret_cast<double2*>(buf + c * kChunk + 2 * tid) = v[c];
+    }
+    __syncthreads();
+
+    for (int j = a.lev0; j <= a.lev1; ++j) {
+        const int s = 1 << (j - 1);
+        const int ps = a.pstart[j];
+        double av[PPT][2], aw[PPT][2], ah[HPT][2];
+        bool hact[HPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) av[k][0] = av[k][1] = aw[k][0] = aw[k][1] = 0.0;
+#pragma unroll
+        for (int c = 0; c < HPT; ++c) {
+            ah[c][0] = ah[c][1] = 0.0;
+            // the last level needs no halo: only the tile is stored
+            hact[c] = (j < a.lev1) && (c * kChunk + 2 * tid >= ps);
+        }
+        if (s == 1)
+            fwd_level<PPT, HPT, true>(lds, a, s, tid, av, aw, ah, hact);
+        else
+            fwd_level<PPT, HPT, false>(lds, a, s, tid, av, aw, ah, hact);
+
+        // ---- W_j straight to HBM -------------------------------------------------
+        double* __restrict__ wrow = a.wout + row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t t = t0 + k * kChunk + 2 * tid;
+            if (VEC2) {
+                if (t < n) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+            } else {
+                if (t < n) wrow[t] = aw[k][0];
+                if (t + 1 < n) wrow[t + 1] = aw[k][1];
+            }
+        }
+        if (j == a.lev1) {
+            double* __restrict__ vrow = a.vout + row * a.v_stride;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * kChunk + 2 * tid;
+                if (VEC2) {
+                    if (t < n) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                } else {
+                    if (t < n) vrow[t] = av[k][0];
+                    if (t + 1 < n) vrow[t + 1] = av[k][1];
+                }
+            }
+        } else {
+            __syncthreads();  // every lane has finished reading V_{j-1}
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                *reinterpret_cast<double2*>(buf + HALO + k * kChunk + 2 * tid) = make_double2(av[k][0], av[k][1]);
+#pragma unroll
+            for (int c = 0; c < HPT; ++c) {
+                if (hact[c]) {
+                    double2 v = make_double2(ah[c][0], ah[c][1]);
+                    if (MODE == kZeroPad) {
+                        // samples left of the signal are zero at every level
+                        const int64_t t = t0 - HALO + c * kChunk + 2 * tid;
+                        if (t < 0) v.x = 0.0;
+                        if (t + 1 < 0) v.y = 0.0;
+                    }
+                    *reinterpret_cast<double2*>(buf + c * kChunk + 2 * tid) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused inverse: levels lev1 down to lev0 of one (row, tile) per workgroup
+// ---------------------------------------------------------------------------
+//
+// Two LDS buffers of M = (PPT + HPT) * 512 doubles: R (running reconstruction)
+// and W (detail band of the level being undone); position p <-> t = t0 + p, the
+// halo is on the right and shrinks as the levels descend.  The next band is
+// fetched from HBM into registers while the current level is computed.
+
+template <int NP, bool S1>
+__device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, const InvArgs& a, int s,
+                                          int tid, double (&acc)[NP][2], const bool (&act)[NP]) {
+    const int base = (2 * tid) * 8;
+    double r1[NP], w1[NP];
+    if (S1) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            r1[k] = act[k] ? *reinterpret_cast<const double*>(ldsR + base + k * (kChunk * 8)) : 0.0;
+            w1[k] = act[k] ? *reinterpret_cast<const double*>(ldsW + base + k * (kChunk * 8)) : 0.0;
+        }
+    }
+    const int lh = a.lh;
+    const int sb = s * 8;
+    int off = 0;
+    double flo = a.taps.lo[0], fhi = a.taps.hi[0];
+    for (int l = 0; l < lh; ++l) {
+        const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (act[k]) {
+                double rx, ry, wx, wy;
+                if (S1) {
+                    // pair (p, p+1) reads positions p+l and p+1+l: slide by one per tap
+                    rx = r1[k];
+                    wx = w1[k];
+                    ry = *reinterpret_cast<const double*>(ldsR + base + k * (kChunk * 8) + off + 8);
+                    wy = *reinterpret_cast<const double*>(ldsW + base + k * (kChunk * 8) + off + 8);
+                    r1[k] = ry;
+                    w1[k] = wy;
+                } else {
+                    const double2 r = *reinterpret_cast<const double2*>(ldsR + base + k * (kChunk * 8) + off);
+                    const double2 w = *reinterpret_cast<const double2*>(ldsW + base + k * (kChunk * 8) + off);
+                    rx = r.x;
+                    ry = r.y;
+                    wx = w.x;
+                    wy = w.y;
+                }
+                // sum += lo[l]*a[idx] + hi[l]*d[idx]
+                acc[k][0] = acc[k][0] + (flo * rx + fhi * wx);
+                acc[k][1] = acc[k][1] + (flo * ry + fhi * wy);
+            }
+        }
+        off += sb;
+        flo = flo_n;
+        fhi = fhi_n;
+    }
+}
+
+template <int NP, int MODE, bool VEC2>
+__device__ __forceinline__ void inv_fetch(const double* __restrict__ src, bool use, int64_t t0,
+                                          int64_t n, int tid, int plimit, double2 (&v)[NP]) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        const int p = c * kChunk + 2 * tid;
+        double2 x = make_double2(0.0, 0.0);
+        if (use && p < plimit) {
+            const int64_t t = t0 + p;
+            if (VEC2) {
+                if (t < n)
+                    x = *reinterpret_cast<const double2*>(src + t);
+                else if (MODE == kPeriodic)
+                    x = *reinterpret_cast<const double2*>(src + mod_wrap(t, n));
+            } else {
+                if (t < n)
+                    x.x = src[t];
+                else if (MODE == kPeriodic)
+                    x.x = src[mod_wrap(t, n)];
+                if (t + 1 < n)
+                    x.y = src[t + 1];
+                else if (MODE == kPeriodic)
+                    x.y = src[mod_wrap(t + 1, n)];
+            }
+        }
+        v[c] = x;
+    }
+}
+
+template <int PPT, int HPT, int MODE, bool VEC2>
+__global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int NP = PPT + HPT;
+    constexpr int M = NP * kChunk;
+    double* bufR = reinterpret_cast<double*>(vw_smem);
+    double* bufW = bufR + M;
+    const char* ldsR = reinterpret_cast<const char*>(bufR);
+    const char* ldsW = reinterpret_cast<const char*>(bufW);
+    constexpr int T = PPT * kChunk;
+    const int tid = threadIdx.x;
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int tile = static_cast<int>(id - row * a.ntiles);
+    const int64_t t0 = static_cast<int64_t>(tile) * T;
+    const int64_t n = a.n;
+    const double* __restrict__ wbase = a.win + row * a.w_row_stride;
+    const double thr = (a.thr_mode != 0) ? a.thr[row] : 0.0;
+
+    double2 pre[NP];
+    // R_{lev1}
+    inv_fetch<NP, MODE, VEC2>(a.rin + row * a.rin_stride, (a.band_mask >> 31) & 1u, t0, n, tid,
+                              a.pend[a.lev1], pre);
+    if (a.first_bad != nullptr) {
+#pragma unroll
+        for (int c = 0; c < PPT; ++c) {
+            const int64_t t = t0 + c * kChunk + 2 * tid;
+            if (t < n && !finite_f64(pre[c].x)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
+            if (t + 1 < n && !finite_f64(pre[c].y)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NP; ++c) *reinterpret_cast<double2*>(bufR + c * kChunk + 2 * tid) = pre[c];
+    // W_{lev1}
+    inv_fetch<NP, MODE, VEC2>(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride,
+                              (a.band_mask >> (a.lev1 - 1)) & 1u, t0, n, tid, a.pend[a.lev1], pre);
+
+    for (int j = a.lev1; j >= a.lev0; --j) {
+        const int s = 1 << (j - 1);
+        // publish W_j (thresholded on the way in when denoising)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            double2 w = pre[c];
+            if (a.thr_mode != 0) {
+                w.x = apply_thr(w.x, thr, a.thr_mode);
+                w.y = apply_thr(w.y, thr, a.thr_mode);
+            }
+            if (a.first_bad != nullptr && c < PPT) {
+                const int64_t t = t0 + c * kChunk + 2 * tid;
+                if (t < n && !finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
+                if (t + 1 < n && !finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+            }
+            *reinterpret_cast<double2*>(bufW + c * kChunk + 2 * tid) = w;
+        }
+        __syncthreads();  // R_j and W_j visible
+        if (j > a.lev0)
+            inv_fetch<NP, MODE, VEC2>(wbase + static_cast<int64_t>(j - 2) * a.w_band_stride,
+                                      (a.band_mask >> (j - 2)) & 1u, t0, n, tid, a.pend[j - 1], pre);
+
+        const int pe = (j > a.lev0) ? a.pend[j - 1] : T;  // the last level only needs the tile
+        double acc[NP][2];
+        bool act[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            acc[k][0] = acc[k][1] = 0.0;
+            act[k] = (k * kChunk + 2 * tid) < pe;
+        }
+        if (s == 1)
+            inv_level<NP, true>(ldsR, ldsW, a, s, tid, acc, act);
+        else
+            inv_level<NP, false>(ldsR, ldsW, a, s, tid, acc, act);
+
+        if (j == a.lev0) {
+            double* __restrict__ orow = a.rout + row * a.rout_stride;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * kChunk + 2 * tid;
+                if (VEC2) {
+                    if (t < n) *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
+                } else {
+                    if (t < n) orow[t] = acc[k][0];
+                    if (t + 1 < n) orow[t + 1] = acc[k][1];
+                }
+            }
+        } else {
+            __syncthreads();  // every lane has finished reading R_j / W_j
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (act[k]) {
+                    double2 v = make_double2(acc[k][0], acc[k][1]);
+                    if (MODE == kZeroPad) {
+                        // samples right of the signal are zero at every level
+                        const int64_t t = t0 + k * kChunk + 2 * tid;
+                        if (t >= n) v.x = 0.0;
+                        if (t + 1 >= n) v.y = 0.0;
+                    }
+                    *reinterpret_cast<double2*>(bufR + k * kChunk + 2 * tid) = v;
+                }
+            }
+            // the barrier at the top of the next iteration publishes R_{j-1}
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic one-level kernels (any boundary, any N / L, truncated filters):
+// one lane per output sample, operands through the cache hierarchy.  Used for
+// SYMMETRIC, for filters longer than the signal and for halos that exceed LDS.
+// ---------------------------------------------------------------------------
+
+struct LevelArgs {
+    const double* in;   // forward: V_{j-1}; inverse: R_j
+    int64_t in_stride;
+    const double* din;  // inverse only: W_j
+    int64_t din_stride;
+    double* out_lo;     // forward: V_j; inverse: R_{j-1}
+    int64_t out_lo_stride;
+    double* out_hi;     // forward: W_j (may be nullptr)
+    int64_t out_hi_stride;
+    int64_t n;
+    int64_t nrows;
+    int64_t stride;     // 2^(j-1)
+    int32_t llo, lhi;   // taps used of lo / hi (after the reference's truncation)
+    int32_t variant;    // inverse SYMMETRIC flavour, see k_level_inv
+    int32_t use_in, use_din;  // 0 = treat the operand as all zeros
+    Taps taps;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_level_fwd(const LevelArgs a) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const int64_t per_row = (a.n + kThreads - 1) / kThreads * kThreads;
+    const int64_t row = gid / per_row;
+    const int64_t t = gid - row * per_row;
+    if (row >= a.nrows || t >= a.n) return;
+    const double* __restrict__ x = a.in + row * a.in_stride;
+    const int64_t n = a.n;
+    const int lmax = a.llo > a.lhi ? a.llo : a.lhi;
+    double slo = 0.0, shi = 0.0;
+    for (int l = 0; l < lmax; ++l) {
+        int64_t idx = t - static_cast<int64_t>(l) * a.stride;
+        bool ok = true;
+        if (MODE == kPeriodic) {
+            if (idx < 0) idx = (idx >= -n) ? idx + n : mod_wrap(idx, n);
+        } else if (MODE == kZeroPad) {
+            ok = idx >= 0;
+        } else {
+            idx = sym_reflect(idx, n);
+        }
+        if (ok) {
+            const double v = x[idx];
+            if (l < a.llo) slo = slo + v * a.taps.lo[l];
+            if (l < a.lhi) shi = shi + v * a.taps.hi[l];
+        }
+    }
+    if (a.out_lo != nullptr) a.out_lo[row * a.out_lo_stride + t] = slo;
+    if (a.out_hi != nullptr) a.out_hi[row * a.out_hi_stride + t] = shi;
+}
+
+// variant (SYMMETRIC only):
+//   0  MultiLevelMODWTTransform.applyScaledInverseMODWT: reflect(t - l*s), the two
+//      products added to the sum one after the other, per-filter length guards
+//   1  MODWTTransform.inverse: reflect(t - l), pair-sum, l < llo
+//   2  MODWTTransform.inverseBatchOptimized: reflect(t + l), pair-sum, l < llo
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) k_level_inv(const LevelArgs a) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const int64_t per_row = (a.n + kThreads - 1) / kThreads * kThreads;
+    const int64_t row = gid / per_row;
+    const int64_t t = gid - row * per_row;
+    if (row >= a.nrows || t >= a.n) return;
+    const double* __restrict__ ap = a.in + row * a.in_stride;
+    const double* __restrict__ dp = a.din + row * a.din_stride;
+    const int64_t n = a.n;
+    double sum = 0.0;
+    if (MODE == kSymmetric && a.variant == 0) {
+        const int lmax = a.llo > a.lhi ? a.llo : a.lhi;
+        for (int l = 0; l < lmax; ++l) {
+            const int64_t idx = sym_reflect(t - static_cast<int64_t>(l) * a.stride, n);
+            if (l < a.llo) sum = sum + a.taps.lo[l] * (a.use_in ? ap[idx] : 0.0);
+            if (l < a.lhi) sum = sum + a.taps.hi[l] * (a.use_din ? dp[idx] : 0.0);
+        }
+    } else {
+        for (int l = 0; l < a.llo; ++l) {
+            int64_t idx;
+            bool ok = true;
+            if (MODE == kPeriodic) {
+                idx = (t + static_cast<int64_t>(l) * a.stride) % n;
+            } else if (MODE == kZeroPad) {
+                idx = t + static_cast<int64_t>(l) * a.stride;
+                ok = idx < n;
+            } else if (a.variant == 1) {
+                idx = sym_reflect(t - static_cast<int64_t>(l) * a.stride, n);
+            } else {
+                idx = sym_reflect(t + static_cast<int64_t>(l) * a.stride, n);
+            }
+            if (ok) {
+                const double av = a.use_in ? ap[idx] : 0.0;
+                const double dv = a.use_din ? dp[idx] : 0.0;
+                sum = sum + (a.taps.lo[l] * av + a.taps.hi[l] * dv);
+            }
+        }
+    }
+    a.out_lo[row * a.out_lo_stride + t] = sum;
+}
+
+// ---------------------------------------------------------------------------
+// element-wise kernels
+// ---------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kThreads) k_threshold(const double* __restrict__ in, double* __restrict__ out,
+                                                        int64_t count, double thr, int mode) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * kThreads;
+    for (; i < count; i += step) out[i] = apply_thr(in[i], thr, mode);
+}
+
+__global__ void __launch_bounds__(kThreads) k_first_non_finite(const double* __restrict__ in, int64_t count,
+                                                               unsigned long long* first_bad) {
+    int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const int64_t step = static_cast<int64_t>(gridDim.x) * kThreads;
+    unsigned long long best = ~0ull;
+    for (; i < count; i += step)
+        if (!finite_f64(in[i]) && static_cast<unsigned long long>(i) < best) best = static_cast<unsigned long long>(i);
+    if (best != ~0ull) atomicMin(first_bad, best);
+}
+
+// Turns the atomicMin cell (initialised to all-ones) into the ABI's "-1 = none".
+__global__ void k_finish_first_bad(unsigned long long* cell, int64_t* out) {
+    const unsigned long long v = *cell;
+    *out = (v == ~0ull) ? -1 : static_cast<int64_t>(v);
+}
+
+// ---------------------------------------------------------------------------
+// universal threshold: exact median of |d_1| per row by radix select
+// ---------------------------------------------------------------------------
+//
+// |x| of a finite double orders like its bit pattern as an unsigned integer, so
+// the k-th order statistic is found by an 8-bit-per-pass radix descent over the
+// keys.  One workgroup per row; the 256-bin histogram of a pass lives in LDS, the
+// bin that holds rank k is located with a wavefront prefix scan (DPP shuffles)
+// plus a 4-entry cross-wave fix-up.  Even N needs ranks N/2-1 and N/2 (the
+// reference averages the two middle elements of the sorted array): the second
+// one is either the same key (duplicates) or the smallest key above the first.
+
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(v, d, 64);
+        if ((threadIdx.x & 63) >= d) v += up;
+    }
+    return v;
+}
+
+// Key source: either the LDS copy of the row (n <= cap) or global memory.
+struct KeySrc {
+    const unsigned long long* lds;
+    const double* glob;
+    __device__ __forceinline__ unsigned long long get(int64_t i) const {
+        if (lds != nullptr) return lds[i];
+        return static_cast<unsigned long long>(__double_as_longlong(glob[i])) & 0x7fffffffffffffffull;
+    }
+};
+
+// Returns the key of rank k (0-based) among n keys; all threads get the result.
+__device__ unsigned long long radix_select(const KeySrc& src, int64_t n, int64_t k, unsigned* hist /*256*/,
+                                           unsigned* wsum /*4*/, unsigned long long* bcast /*2*/) {
+    const int tid = threadIdx.x;
+    unsigned long long prefix = 0;
+    int64_t kk = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+        for (int64_t i = tid; i < n; i += kThreads) {
+            const unsigned long long key = src.get(i);
+            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+        }
+        __syncthreads();
+        // inclusive scan of the 256 bins: bin `tid` belongs to lane tid
+        const unsigned cnt = hist[tid];
+        unsigned inc = wave_inclusive_scan(cnt);
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        unsigned add = 0;
+        for (int w = 0; w < (tid >> 6); ++w) add += wsum[w];
+        inc += add;
+        const unsigned exc = inc - cnt;
+        if (cnt != 0 && static_cast<int64_t>(exc) <= kk && kk < static_cast<int64_t>(inc)) {
+            bcast[0] = prefix | (static_cast<unsigned long long>(tid) << shift);
+            bcast[1] = static_cast<unsigned long long>(kk - exc);
+        }
+        __syncthreads();
+        prefix = bcast[0];
+        kk = static_cast<int64_t>(bcast[1]);
+        __syncthreads();
+    }
+    return prefix;
+}
+
+struct MedianArgs {
+    const double* d1;      // band d_1 of row r at d1 + r*row_stride
+    int64_t row_stride;
+    int64_t n;
+    int64_t nrows;
+    double sqrt_2_ln_n;
+    double* thr_out;       // [nrows]
+    int32_t lds_cap;       // rows up to this length are copied into LDS
+};
+
+__global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianArgs a) {
+    extern __shared__ double2 vw_smem[];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned long long bcast[2];
+    __shared__ unsigned long long red[kThreads];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n;
+    const double* __restrict__ d = a.d1 + row * a.row_stride;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(vw_smem);
+
+    KeySrc src;
+    src.glob = d;
+    src.lds = nullptr;
+    if (n <= a.lds_cap) {
+        for (int64_t i = tid; i < n; i += kThreads)
+            keys[i] = static_cast<unsigned long long>(__double_as_longlong(d[i])) & 0x7fffffffffffffffull;
+        src.lds = keys;
+        __syncthreads();
+    }
+    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+    const unsigned long long v1 = radix_select(src, n, k1, hist, wsum, bcast);
+    double median;
+    if (n % 2 != 0) {
+        median = __longlong_as_double(static_cast<long long>(v1));
+    } else {
+        // rank k1+1: v1 again if at least k1+2 keys are <= v1, else the smallest key above v1
+        unsigned long long le = 0, above = ~0ull;
+        for (int64_t i = tid; i < n; i += kThreads) {
+            const unsigned long long key = src.get(i);
+            if (key <= v1)
+                ++le;
+            else if (key < above)
+                above = key;
+        }
+        red[tid] = le;
+        __syncthreads();
+        for (int w = kThreads / 2; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        const unsigned long long le_total = red[0];
+        __syncthreads();
+        red[tid] = above;
+        __syncthreads();
+        for (int w = kThreads / 2; w > 0; w >>= 1) {
+            if (tid < w && red[tid + w] < red[tid]) red[tid] = red[tid + w];
+            __syncthreads();
+        }
+        const unsigned long long v2 = (static_cast<int64_t>(le_total) >= k1 + 2) ? v1 : red[0];
+        median = (__longlong_as_double(static_cast<long long>(v1)) +
+                  __longlong_as_double(static_cast<long long>(v2))) / 2.0;
+    }
+    if (tid == 0) {
+        const double sigma = median / 0.6745;
+        a.thr_out[row] = sigma * a.sqrt_2_ln_n;
+    }
+}
+
+}  // namespace vw
