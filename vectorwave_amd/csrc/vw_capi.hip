@@ -161,7 +161,8 @@ struct TileCfg {
 static const TileCfg kCfgs[] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {8, 2}, {8, 4}, {8, 10}};
 
 static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileCfg* out) {
-    int hpt_need = static_cast<int>((halo + kChunk - 1) / kChunk);
+    // two samples of slack: pair alignment may start a pair one sample outside the exact need
+    int hpt_need = static_cast<int>((halo + 2 + kChunk - 1) / kChunk);
     if (hpt_need < 1) hpt_need = 1;
     int64_t row_chunks = (n + kChunk - 1) / kChunk;  // chunks that cover one row
     if (row_chunks < 1) row_chunks = 1;
@@ -373,7 +374,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                     while (hi + 1 <= levels) {
                         TileCfg c2;
                         const int64_t hneed = fwd_halo(j, hi + 1, lh, lg, nullptr);
-                        if (hneed > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
+                        if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
                         if (!pick_cfg(n, hneed, ctx->lds_limit, false, &c2)) break;
                         st.cfg = c2;
                         ++hi;
@@ -592,7 +593,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                     while (lo - 1 >= 1) {
                         TileCfg c2;
                         const int64_t hneed = inv_halo(lo - 1, j, lhr);
-                        if (hneed > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
+                        if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
                         if (!pick_cfg(n, hneed, ctx->lds_limit, true, &c2)) break;
                         st.cfg = c2;
                         --lo;
@@ -650,6 +651,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.thr_mode = thr_mode;
             a.thr = thr_rows;
             a.first_bad = first_bad_cell;
+            a.check_rin = first ? 1 : 0;
             a.taps = taps;
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;

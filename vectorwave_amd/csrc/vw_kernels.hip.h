@@ -72,7 +72,8 @@ struct InvArgs {
     uint32_t band_mask;    // bit (j-1): use W_j, else zeros; bit 31: use rin, else zeros
     int32_t thr_mode;      // 0 none, 1 soft, 2 hard: applied to W_j as it is loaded
     const double* thr;     // per-row threshold (thr_mode != 0)
-    unsigned long long* first_bad;
+    unsigned long long* first_bad;  // flat index into the coefficient block of the first NaN/Inf
+    int32_t check_rin;     // rin is the a_J band of the block (top group): include it in the check
     Taps taps;
 };
 
@@ -459,12 +460,13 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
     // R_{lev1}
     inv_fetch<NP, MODE, VEC2>(a.rin + row * a.rin_stride, (a.band_mask >> 31) & 1u, t0, n, tid,
                               a.pend[a.lev1], pre);
-    if (a.first_bad != nullptr) {
+    if (a.first_bad != nullptr && a.check_rin) {
+        const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
 #pragma unroll
         for (int c = 0; c < PPT; ++c) {
             const int64_t t = t0 + c * kChunk + 2 * tid;
-            if (t < n && !finite_f64(pre[c].x)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
-            if (t + 1 < n && !finite_f64(pre[c].y)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+            if (t < n && !finite_f64(pre[c].x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+            if (t + 1 < n && !finite_f64(pre[c].y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
         }
     }
 #pragma unroll
@@ -484,9 +486,10 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
                 w.y = apply_thr(w.y, thr, a.thr_mode);
             }
             if (a.first_bad != nullptr && c < PPT) {
+                const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
                 const int64_t t = t0 + c * kChunk + 2 * tid;
-                if (t < n && !finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
-                if (t + 1 < n && !finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+                if (t < n && !finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                if (t + 1 < n && !finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
             }
             *reinterpret_cast<double2*>(bufW + c * kChunk + 2 * tid) = w;
         }
@@ -661,12 +664,6 @@ __global__ void __launch_bounds__(kThreads) k_first_non_finite(const double* __r
     for (; i < count; i += step)
         if (!finite_f64(in[i]) && static_cast<unsigned long long>(i) < best) best = static_cast<unsigned long long>(i);
     if (best != ~0ull) atomicMin(first_bad, best);
-}
-
-// Turns the atomicMin cell (initialised to all-ones) into the ABI's "-1 = none".
-__global__ void k_finish_first_bad(unsigned long long* cell, int64_t* out) {
-    const unsigned long long v = *cell;
-    *out = (v == ~0ull) ? -1 : static_cast<int64_t>(v);
 }
 
 // ---------------------------------------------------------------------------
