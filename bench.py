@@ -229,7 +229,7 @@ def cpu_baseline(o, w, J, n, args):
     if rows <= 0:
         probe = max(cores, 8)
         tp = run(probe)
-        rows = int(max(probe, min(4096, probe * 12.0 / max(tp, 1e-6))))  # aim at ~12 s
+        rows = int(max(probe, min(32768, probe * 15.0 / max(tp, 1e-6))))  # aim at ~15 s
     el = run(rows)
     return {
         "value": round(rows * n / el / 1e9, 5), "unit": "Gsamples/s", "cores": cores, "kind": "port",

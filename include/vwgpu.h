@@ -21,12 +21,15 @@
  *     scaling (modwt/MODWTTransform.java:133-142) itself, in binary64, so host
  *     and device agree bit for bit.
  *   - "_dev" entry points take DEVICE pointers (hipMalloc'd or any framework's
- *     device allocation on the context's GPU) and enqueue on `stream`
- *     (a hipStream_t passed as void*; NULL = the context's own stream) without
- *     synchronising.  The others take HOST pointers, stage through device
- *     buffers owned by the context, and return when the result is in the
- *     caller's buffer.  The caller owns every buffer it passes; the library
- *     keeps no pointer after return.
+ *     device allocation on the context's GPU) and enqueue on `stream` (a
+ *     hipStream_t passed as void*; NULL is HIP's default stream, as everywhere in
+ *     HIP) without synchronising.  Multi-pass plans keep their intermediate
+ *     plane in a buffer owned by the context, so calls that share a context must
+ *     be ordered on one stream (use one context per concurrent stream).  The
+ *     other entry points take HOST pointers, stage through device buffers owned
+ *     by the context on the context's own stream, and return when the result
+ *     is in the caller's buffer.  The caller owns every buffer it passes; the
+ *     library keeps no pointer after return.
  *   - arithmetic is the reference's scalar path: products and sums rounded
  *     separately (no FMA contraction), taps added in ascending order.
  */

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvwgpu.so")
+# VW_LIBVWGPU lets the tuning harness swap in an experimental build of the same ABI
+LIB_PATH = os.environ.get("VW_LIBVWGPU") or os.path.join(_HERE, "libvwgpu.so")
 
 # status codes (include/vwgpu.h)
 VW_OK = 0

@@ -64,7 +64,7 @@ static int set_err(vw_ctx* ctx, int code, const char* fmt, ...) {
 static int ensure(vw_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p != nullptr) return VW_OK;
     if (b.p != nullptr) {
-        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VW_HIP(ctx, hipDeviceSynchronize());  // the buffer may be in use on a caller's stream
         VW_HIP(ctx, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -160,12 +160,28 @@ struct TileCfg {
 // Instantiated (PPT, HPT) pairs.  Keep in sync with the dispatch switch below.
 static const TileCfg kCfgs[] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {8, 2}, {8, 4}, {8, 10}};
 
+// Tuning hook: VW_FWD_TILE / VW_INV_TILE = "<ppt>,<hpt>" force an instantiated tile shape
+// (ignored when the halo does not fit it).
+static bool env_cfg(bool inverse, int hpt_need, TileCfg* out) {
+    const char* e = getenv(inverse ? "VW_INV_TILE" : "VW_FWD_TILE");
+    if (e == nullptr) return false;
+    int p = 0, h = 0;
+    if (sscanf(e, "%d,%d", &p, &h) != 2) return false;
+    for (const TileCfg& c : kCfgs)
+        if (c.ppt == p && c.hpt == h && h >= hpt_need) {
+            *out = c;
+            return true;
+        }
+    return false;
+}
+
 static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileCfg* out) {
     // two samples of slack: pair alignment may start a pair one sample outside the exact need
     int hpt_need = static_cast<int>((halo + 2 + kChunk - 1) / kChunk);
     if (hpt_need < 1) hpt_need = 1;
     int64_t row_chunks = (n + kChunk - 1) / kChunk;  // chunks that cover one row
     if (row_chunks < 1) row_chunks = 1;
+    if (env_cfg(inverse, hpt_need, out)) return true;
     const int ncfg = static_cast<int>(sizeof(kCfgs) / sizeof(kCfgs[0]));
     // smallest instantiated halo that covers the need and fits LDS
     int hpt = 0;
@@ -187,7 +203,11 @@ static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileC
             continue;
         }
         const TileCfg& b = kCfgs[best];
-        const bool c_in = c.ppt <= row_chunks, b_in = b.ppt <= row_chunks;
+        // measured on MI355X (DB4 J=6, 65536 x 16384): 2048-sample tiles run a few percent faster
+        // than 4096-sample ones in both directions (more resident workgroups per CU outweigh the
+        // extra halo), so tiles above 4 chunks are used only when the halo forces them
+        const int cap = 4;
+        const bool c_in = c.ppt <= row_chunks && c.ppt <= cap, b_in = b.ppt <= row_chunks && b.ppt <= cap;
         if ((c_in && (!b_in || c.ppt > b.ppt)) || (!c_in && !b_in && c.ppt < b.ppt)) best = i;
     }
     *out = kCfgs[best];
@@ -414,6 +434,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             a.vout = vout;
             a.v_stride = vstride;
             a.n = n;
+            a.n_store = n;
             a.nrows = b;
             const int T = st.cfg.ppt * kChunk;
             a.ntiles = static_cast<int32_t>((n + T - 1) / T);
@@ -421,6 +442,10 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             a.lev1 = st.lev1;
             a.lh = lh;
             a.lg = lg;
+            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
+                if (strstr(dbg, "nostore")) a.n_store = 0;
+                if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
+            }
             int64_t hn[kMaxLevels + 2] = {0};
             fwd_halo(st.lev0, st.lev1, lh, lg, hn);
             const int64_t halo = static_cast<int64_t>(st.cfg.hpt) * kChunk;
@@ -494,7 +519,7 @@ extern "C" int32_t vw_modwt_forward_batch_dev(vw_ctx* ctx, const double* x_dev, 
     if (b == 0) return VW_OK;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned long long* cell = nullptr;
     if ((flags & VW_FLAG_CHECK_FINITE) && first_bad_dev != nullptr) {
         VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
@@ -535,7 +560,7 @@ extern "C" int32_t vw_modwt_forward_batch(vw_ctx* ctx, const double* x, int64_t 
         const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
         VW_HIP(ctx, hipMemcpyAsync(dx, x + r0 * n, static_cast<size_t>(nr) * n * 8, hipMemcpyHostToDevice, ctx->stream));
         rc = vw_modwt_forward_batch_dev(ctx, dx, nr, n, levels, h, lh, g, lg, boundary, flags | VW_FLAG_NO_LEVEL_CHECK,
-                                        dc, chk ? cell : nullptr, nullptr);
+                                        dc, chk ? cell : nullptr, ctx->stream);
         if (rc != VW_OK) return rc;
         VW_HIP(ctx, hipMemcpyAsync(coeffs + r0 * (levels + 1) * n, dc, static_cast<size_t>(nr) * (levels + 1) * n * 8,
                                    hipMemcpyDeviceToHost, ctx->stream));
@@ -632,6 +657,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.rout = rout;
             a.rout_stride = rstride;
             a.n = n;
+            a.n_store = n;
             a.nrows = b;
             const int T = st.cfg.ppt * kChunk;
             const int M = (st.cfg.ppt + st.cfg.hpt) * kChunk;
@@ -653,6 +679,10 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
+            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
+                if (strstr(dbg, "nostore")) a.n_store = 0;
+                if (strstr(dbg, "nocompute")) a.lh = 0;
+            }
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
@@ -726,7 +756,7 @@ extern "C" int32_t vw_modwt_inverse_bands_batch_dev(vw_ctx* ctx, const double* c
     if (b == 0) return VW_OK;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     return inverse_dev(ctx, coeffs_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, band_mask, 0, nullptr, x_dev,
                        nullptr, s);
 }
@@ -740,7 +770,7 @@ extern "C" int32_t vw_modwt_inverse_batch_dev(vw_ctx* ctx, const double* coeffs_
     if (b == 0) return VW_OK;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned long long* cell = nullptr;
     if ((flags & VW_FLAG_CHECK_FINITE) && first_bad_dev != nullptr) {
         VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
@@ -775,10 +805,10 @@ static int inverse_host(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n,
         VW_HIP(ctx, hipMemcpyAsync(dc, coeffs + r0 * (levels + 1) * n, static_cast<size_t>(nr) * (levels + 1) * n * 8,
                                    hipMemcpyHostToDevice, ctx->stream));
         if (use_mask)
-            rc = vw_modwt_inverse_bands_batch_dev(ctx, dc, nr, n, levels, hr, lhr, gr, lgr, boundary, band_mask, dx, nullptr);
+            rc = vw_modwt_inverse_bands_batch_dev(ctx, dc, nr, n, levels, hr, lhr, gr, lgr, boundary, band_mask, dx, ctx->stream);
         else
             rc = vw_modwt_inverse_batch_dev(ctx, dc, nr, n, levels, hr, lhr, gr, lgr, boundary, flags, dx,
-                                            chk ? cell : nullptr, nullptr);
+                                            chk ? cell : nullptr, ctx->stream);
         if (rc != VW_OK) return rc;
         VW_HIP(ctx, hipMemcpyAsync(x + r0 * n, dx, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         int64_t bad = -1;
@@ -817,7 +847,7 @@ extern "C" int32_t vw_threshold_dev(vw_ctx* ctx, const double* in_dev, int64_t c
     if (threshold < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold must be non-negative");
     if (count == 0) return VW_OK;
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t blocks = (count + kThreads - 1) / kThreads;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_threshold, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, in_dev, out_dev, count,
@@ -841,7 +871,7 @@ extern "C" int32_t vw_threshold(vw_ctx* ctx, const double* in, int64_t count, do
     }
     double* d = static_cast<double*>(ctx->stage_in.p);
     VW_HIP(ctx, hipMemcpyAsync(d, in, static_cast<size_t>(count) * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = vw_threshold_dev(ctx, d, count, threshold, soft, d, nullptr);
+    int rc = vw_threshold_dev(ctx, d, count, threshold, soft, d, ctx->stream);
     if (rc != VW_OK) return rc;
     VW_HIP(ctx, hipMemcpyAsync(out, d, static_cast<size_t>(count) * 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -878,7 +908,7 @@ extern "C" int32_t vw_swt_universal_threshold_batch_dev(vw_ctx* ctx, const doubl
     if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
     if (b == 0) return VW_OK;
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     return universal_threshold_dev(ctx, coeffs_dev, b, n, levels, sqrt_2_ln_n, thresholds_dev, s);
 }
 
@@ -957,7 +987,7 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
     if (b == 0) return VW_OK;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t need = vw_swt_denoise_workspace_bytes(b, n, levels);
     char* wsb;
     if (workspace_dev != nullptr) {
@@ -1030,7 +1060,7 @@ extern "C" int32_t vw_swt_denoise_batch(vw_ctx* ctx, const double* x, int64_t b,
         const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
         VW_HIP(ctx, hipMemcpyAsync(dx, x + r0 * n, static_cast<size_t>(nr) * n * 8, hipMemcpyHostToDevice, ctx->stream));
         rc = vw_swt_denoise_batch_dev(ctx, dx, nr, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold,
-                                      sqrt_2_ln_n, soft, dy, thresholds_out != nullptr ? dthr : nullptr, nullptr, 0, nullptr);
+                                      sqrt_2_ln_n, soft, dy, thresholds_out != nullptr ? dthr : nullptr, nullptr, 0, ctx->stream);
         if (rc != VW_OK) return rc;
         VW_HIP(ctx, hipMemcpyAsync(y + r0 * n, dy, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (thresholds_out != nullptr)
@@ -1055,7 +1085,7 @@ extern "C" int32_t vw_modwt_convolve_batch_dev(vw_ctx* ctx, const double* x_dev,
     if (b > 0 && (x_dev == nullptr || out_dev == nullptr)) return set_err(ctx, VW_E_NULL, "signal cannot be null");
     if (b == 0) return VW_OK;
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     LevelArgs a;
     memset(&a, 0, sizeof(a));
     a.in = x_dev;
@@ -1104,7 +1134,7 @@ extern "C" int32_t vw_modwt_convolve_batch(vw_ctx* ctx, const double* x, int64_t
     double* dx = static_cast<double*>(ctx->stage_in.p);
     double* dy = static_cast<double*>(ctx->stage_out.p);
     VW_HIP(ctx, hipMemcpyAsync(dx, x, static_cast<size_t>(b) * n * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = vw_modwt_convolve_batch_dev(ctx, dx, b, n, filter, filter_len, level, boundary, dy, nullptr);
+    rc = vw_modwt_convolve_batch_dev(ctx, dx, b, n, filter, filter_len, level, boundary, dy, ctx->stream);
     if (rc != VW_OK) return rc;
     VW_HIP(ctx, hipMemcpyAsync(out, dy, static_cast<size_t>(b) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1118,7 +1148,7 @@ extern "C" int32_t vw_first_non_finite_dev(vw_ctx* ctx, const double* x_dev, int
     if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
     if (count > 0 && x_dev == nullptr) return set_err(ctx, VW_E_NULL, "signal cannot be null");
     VW_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream != nullptr ? static_cast<hipStream_t>(stream) : ctx->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     VW_HIP(ctx, hipMemsetAsync(first_bad_dev, 0xff, 8, s));
     if (count == 0) return VW_OK;
     int64_t blocks = (count + kThreads - 1) / kThreads;
@@ -1146,7 +1176,7 @@ extern "C" int32_t vw_first_non_finite(vw_ctx* ctx, const double* x, int64_t cou
     double* d = static_cast<double*>(ctx->stage_in.p);
     int64_t* cell = static_cast<int64_t*>(ctx->cell.p);
     VW_HIP(ctx, hipMemcpyAsync(d, x, static_cast<size_t>(count) * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = vw_first_non_finite_dev(ctx, d, count, cell, nullptr);
+    int rc = vw_first_non_finite_dev(ctx, d, count, cell, ctx->stream);
     if (rc != VW_OK) return rc;
     VW_HIP(ctx, hipMemcpyAsync(first_bad, cell, 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));

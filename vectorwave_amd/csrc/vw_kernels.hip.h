@@ -46,6 +46,7 @@ struct FwdArgs {
     double* vout;          // V_{lev1}
     int64_t v_stride;
     int64_t n;
+    int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels computed by this launch (inclusive)
@@ -64,6 +65,7 @@ struct InvArgs {
     double* rout;          // R_{lev0-1}
     int64_t rout_stride;
     int64_t n;
+    int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
@@ -90,6 +92,15 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblk) {
     const int64_t x = bid & 7, k = bid >> 3;
     const int64_t base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + k;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
+// vector-memory counter, i.e. it would wait for every global store (and every
+// prefetch load) issued so far -- here those must stay in flight across the
+// per-level barriers.  LDS is coherent within the CU, so "my LDS operations have
+// completed" + s_barrier is all the tile hand-off between waves needs.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n) {
@@ -136,44 +147,49 @@ __device__ __forceinline__ double apply_thr(double c, double thr, int mode) {
 // where the shrinking halo still needs it).  Results stay in registers across
 // the barrier and overwrite the buffer in place, so one buffer serves all levels.
 
+// Halo chunks are switched on per WAVE (a scalar branch), never per lane: a lane
+// of an active wave that lies left of the needed zone recomputes the first
+// needed pair instead (its address is clamped, its result is not written back).
+// Per-lane predicates inside the tap loop would split every tap into
+// exec-masked blocks with their own LDS waits.
 template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI>
-__device__ __forceinline__ void fwd_tap(const char* lds, int baseT, int baseH, int off, double flo,
+__device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&hbase)[HPT], int off, double flo,
                                         double fhi, double (&av)[PPT][2], double (&aw)[PPT][2],
                                         double (&ah)[HPT][2], double (&xp)[PPT], double (&xph)[HPT],
-                                        const bool (&hact)[HPT]) {
+                                        const bool (&wact)[HPT]) {
+    double2 xt[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        double x0, x1;
         if (S1) {
-            x0 = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) - off);
-            x1 = xp[k];
-            xp[k] = x0;
+            xt[k].x = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) - off);
+            xt[k].y = xp[k];
+            xp[k] = xt[k].x;
         } else {
-            const double2 x = *reinterpret_cast<const double2*>(lds + baseT + k * (kChunk * 8) - off);
-            x0 = x.x;
-            x1 = x.y;
+            xt[k] = *reinterpret_cast<const double2*>(lds + baseT + k * (kChunk * 8) - off);
         }
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
         if (DO_LO) {
-            av[k][0] = av[k][0] + x0 * flo;
-            av[k][1] = av[k][1] + x1 * flo;
+            av[k][0] = av[k][0] + xt[k].x * flo;
+            av[k][1] = av[k][1] + xt[k].y * flo;
         }
         if (DO_HI) {
-            aw[k][0] = aw[k][0] + x0 * fhi;
-            aw[k][1] = aw[k][1] + x1 * fhi;
+            aw[k][0] = aw[k][0] + xt[k].x * fhi;
+            aw[k][1] = aw[k][1] + xt[k].y * fhi;
         }
     }
     if (DO_LO) {
 #pragma unroll
         for (int c = 0; c < HPT; ++c) {
-            if (hact[c]) {
+            if (wact[c]) {  // wave-uniform
                 double x0, x1;
                 if (S1) {
-                    x0 = *reinterpret_cast<const double*>(lds + baseH + c * (kChunk * 8) - off);
+                    x0 = *reinterpret_cast<const double*>(lds + hbase[c] - off);
                     x1 = xph[c];
                     xph[c] = x0;
                 } else {
-                    const double2 x =
-                        *reinterpret_cast<const double2*>(lds + baseH + c * (kChunk * 8) - off);
+                    const double2 x = *reinterpret_cast<const double2*>(lds + hbase[c] - off);
                     x0 = x.x;
                     x1 = x.y;
                 }
@@ -187,10 +203,9 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, int baseH, i
 template <int PPT, int HPT, bool S1>
 __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int s, int tid,
                                           double (&av)[PPT][2], double (&aw)[PPT][2],
-                                          double (&ah)[HPT][2], const bool (&hact)[HPT]) {
+                                          double (&ah)[HPT][2], const int (&hbase)[HPT], const bool (&wact)[HPT]) {
     constexpr int HALO = HPT * kChunk;
     const int baseT = (HALO + 2 * tid) * 8;
-    const int baseH = (2 * tid) * 8;
     double xp[PPT], xph[HPT];
     if (S1) {
 #pragma unroll
@@ -198,7 +213,7 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
             xp[k] = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) + 8);
 #pragma unroll
         for (int c = 0; c < HPT; ++c)
-            xph[c] = hact[c] ? *reinterpret_cast<const double*>(lds + baseH + c * (kChunk * 8) + 8) : 0.0;
+            xph[c] = wact[c] ? *reinterpret_cast<const double*>(lds + hbase[c] + 8) : 0.0;
     }
     const int lh = a.lh, lg = a.lg;
     const int lmin = lh < lg ? lh : lg;
@@ -208,20 +223,20 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
     double flo = a.taps.lo[0], fhi = a.taps.hi[0];
     for (; l < lmin; ++l) {
         const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, true, true>(lds, baseT, baseH, off, flo, fhi, av, aw, ah, xp, xph, hact);
+        fwd_tap<PPT, HPT, S1, true, true>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
         fhi = fhi_n;
     }
     for (; l < lh; ++l) {  // low-pass longer than high-pass
         const double flo_n = a.taps.lo[l + 1];
-        fwd_tap<PPT, HPT, S1, true, false>(lds, baseT, baseH, off, flo, 0.0, av, aw, ah, xp, xph, hact);
+        fwd_tap<PPT, HPT, S1, true, false>(lds, baseT, hbase, off, flo, 0.0, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
     }
     for (; l < lg; ++l) {  // high-pass longer than low-pass
         const double fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, false, true>(lds, baseT, baseH, off, 0.0, fhi, av, aw, ah, xp, xph, hact);
+        fwd_tap<PPT, HPT, S1, false, true>(lds, baseT, hbase, off, 0.0, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         fhi = fhi_n;
     }
@@ -241,6 +256,7 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
     const int tile = static_cast<int>(id - row * a.ntiles);
     const int64_t t0 = static_cast<int64_t>(tile) * T;
     const int64_t n = a.n;
+    const int64_t ns = a.n_store;
     const double* __restrict__ inrow = a.in + row * a.in_stride;
 
     // ---- stage V_{lev0-1}[t0-HALO, t0+T) into LDS --------------------------------
@@ -282,25 +298,30 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
         for (int c = 0; c < HPT + PPT; ++c)
             *reinterpret_cast<double2*>(buf + c * kChunk + 2 * tid) = v[c];
     }
-    __syncthreads();
+    lds_barrier();
 
     for (int j = a.lev0; j <= a.lev1; ++j) {
         const int s = 1 << (j - 1);
         const int ps = a.pstart[j];
         double av[PPT][2], aw[PPT][2], ah[HPT][2];
-        bool hact[HPT];
+        bool wact[HPT], hwrite[HPT];
+        int hbase[HPT];
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) av[k][0] = av[k][1] = aw[k][0] = aw[k][1] = 0.0;
 #pragma unroll
         for (int c = 0; c < HPT; ++c) {
             ah[c][0] = ah[c][1] = 0.0;
+            const int p = c * kChunk + 2 * tid;
             // the last level needs no halo: only the tile is stored
-            hact[c] = (j < a.lev1) && (c * kChunk + 2 * tid >= ps);
+            wact[c] = (j < a.lev1) && (c * kChunk + 128 * wave + 128 > ps);
+            hwrite[c] = wact[c] && (p >= ps);
+            hbase[c] = (p >= ps ? p : ps) * 8;
         }
         if (s == 1)
-            fwd_level<PPT, HPT, true>(lds, a, s, tid, av, aw, ah, hact);
+            fwd_level<PPT, HPT, true>(lds, a, s, tid, av, aw, ah, hbase, wact);
         else
-            fwd_level<PPT, HPT, false>(lds, a, s, tid, av, aw, ah, hact);
+            fwd_level<PPT, HPT, false>(lds, a, s, tid, av, aw, ah, hbase, wact);
 
         // ---- W_j straight to HBM -------------------------------------------------
         double* __restrict__ wrow = a.wout + row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
@@ -308,10 +329,10 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
         for (int k = 0; k < PPT; ++k) {
             const int64_t t = t0 + k * kChunk + 2 * tid;
             if (VEC2) {
-                if (t < n) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
             } else {
-                if (t < n) wrow[t] = aw[k][0];
-                if (t + 1 < n) wrow[t + 1] = aw[k][1];
+                if (t < ns) wrow[t] = aw[k][0];
+                if (t + 1 < ns) wrow[t + 1] = aw[k][1];
             }
         }
         if (j == a.lev1) {
@@ -320,20 +341,20 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
             for (int k = 0; k < PPT; ++k) {
                 const int64_t t = t0 + k * kChunk + 2 * tid;
                 if (VEC2) {
-                    if (t < n) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                    if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
                 } else {
-                    if (t < n) vrow[t] = av[k][0];
-                    if (t + 1 < n) vrow[t + 1] = av[k][1];
+                    if (t < ns) vrow[t] = av[k][0];
+                    if (t + 1 < ns) vrow[t + 1] = av[k][1];
                 }
             }
         } else {
-            __syncthreads();  // every lane has finished reading V_{j-1}
+            lds_barrier();  // every lane has finished reading V_{j-1}
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
                 *reinterpret_cast<double2*>(buf + HALO + k * kChunk + 2 * tid) = make_double2(av[k][0], av[k][1]);
 #pragma unroll
             for (int c = 0; c < HPT; ++c) {
-                if (hact[c]) {
+                if (hwrite[c]) {
                     double2 v = make_double2(ah[c][0], ah[c][1]);
                     if (MODE == kZeroPad) {
                         // samples left of the signal are zero at every level
@@ -344,7 +365,7 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
                     *reinterpret_cast<double2*>(buf + c * kChunk + 2 * tid) = v;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -358,16 +379,19 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
 // halo is on the right and shrinks as the levels descend.  The next band is
 // fetched from HBM into registers while the current level is computed.
 
-template <int NP, bool S1>
+// Tile chunks (k < PPT) are always computed; halo chunks are switched on per
+// wave, lanes right of the needed zone recompute the last needed pair (clamped
+// address, result not written back) -- see fwd_tap.
+template <int PPT, int NP, bool S1>
 __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, const InvArgs& a, int s,
-                                          int tid, double (&acc)[NP][2], const bool (&act)[NP]) {
-    const int base = (2 * tid) * 8;
+                                          double (&acc)[NP][2], const int (&pb)[NP], const bool (&wact)[NP]) {
     double r1[NP], w1[NP];
     if (S1) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            r1[k] = act[k] ? *reinterpret_cast<const double*>(ldsR + base + k * (kChunk * 8)) : 0.0;
-            w1[k] = act[k] ? *reinterpret_cast<const double*>(ldsW + base + k * (kChunk * 8)) : 0.0;
+            const bool on = (k < PPT) || wact[k];
+            r1[k] = on ? *reinterpret_cast<const double*>(ldsR + pb[k]) : 0.0;
+            w1[k] = on ? *reinterpret_cast<const double*>(ldsW + pb[k]) : 0.0;
         }
     }
     const int lh = a.lh;
@@ -376,29 +400,30 @@ __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, co
     double flo = a.taps.lo[0], fhi = a.taps.hi[0];
     for (int l = 0; l < lh; ++l) {
         const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
+        double2 r[NP], w[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            if (act[k]) {
-                double rx, ry, wx, wy;
+            if ((k < PPT) || wact[k]) {
                 if (S1) {
                     // pair (p, p+1) reads positions p+l and p+1+l: slide by one per tap
-                    rx = r1[k];
-                    wx = w1[k];
-                    ry = *reinterpret_cast<const double*>(ldsR + base + k * (kChunk * 8) + off + 8);
-                    wy = *reinterpret_cast<const double*>(ldsW + base + k * (kChunk * 8) + off + 8);
-                    r1[k] = ry;
-                    w1[k] = wy;
+                    r[k].x = r1[k];
+                    w[k].x = w1[k];
+                    r[k].y = *reinterpret_cast<const double*>(ldsR + pb[k] + off + 8);
+                    w[k].y = *reinterpret_cast<const double*>(ldsW + pb[k] + off + 8);
+                    r1[k] = r[k].y;
+                    w1[k] = w[k].y;
                 } else {
-                    const double2 r = *reinterpret_cast<const double2*>(ldsR + base + k * (kChunk * 8) + off);
-                    const double2 w = *reinterpret_cast<const double2*>(ldsW + base + k * (kChunk * 8) + off);
-                    rx = r.x;
-                    ry = r.y;
-                    wx = w.x;
-                    wy = w.y;
+                    r[k] = *reinterpret_cast<const double2*>(ldsR + pb[k] + off);
+                    w[k] = *reinterpret_cast<const double2*>(ldsW + pb[k] + off);
                 }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if ((k < PPT) || wact[k]) {
                 // sum += lo[l]*a[idx] + hi[l]*d[idx]
-                acc[k][0] = acc[k][0] + (flo * rx + fhi * wx);
-                acc[k][1] = acc[k][1] + (flo * ry + fhi * wy);
+                acc[k][0] = acc[k][0] + (flo * r[k].x + fhi * w[k].x);
+                acc[k][1] = acc[k][1] + (flo * r[k].y + fhi * w[k].y);
             }
         }
         off += sb;
@@ -493,23 +518,28 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
             }
             *reinterpret_cast<double2*>(bufW + c * kChunk + 2 * tid) = w;
         }
-        __syncthreads();  // R_j and W_j visible
+        lds_barrier();  // R_j and W_j visible
         if (j > a.lev0)
             inv_fetch<NP, MODE, VEC2>(wbase + static_cast<int64_t>(j - 2) * a.w_band_stride,
                                       (a.band_mask >> (j - 2)) & 1u, t0, n, tid, a.pend[j - 1], pre);
 
         const int pe = (j > a.lev0) ? a.pend[j - 1] : T;  // the last level only needs the tile
         double acc[NP][2];
-        bool act[NP];
+        bool wact[NP], wr[NP];
+        int pb[NP];
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             acc[k][0] = acc[k][1] = 0.0;
-            act[k] = (k * kChunk + 2 * tid) < pe;
+            const int p = k * kChunk + 2 * tid;
+            wact[k] = (k * kChunk + 128 * wave) < pe;
+            wr[k] = p < pe;
+            pb[k] = ((k < PPT || p < pe) ? p : pe - 2) * 8;
         }
         if (s == 1)
-            inv_level<NP, true>(ldsR, ldsW, a, s, tid, acc, act);
+            inv_level<PPT, NP, true>(ldsR, ldsW, a, s, acc, pb, wact);
         else
-            inv_level<NP, false>(ldsR, ldsW, a, s, tid, acc, act);
+            inv_level<PPT, NP, false>(ldsR, ldsW, a, s, acc, pb, wact);
 
         if (j == a.lev0) {
             double* __restrict__ orow = a.rout + row * a.rout_stride;
@@ -517,17 +547,17 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
             for (int k = 0; k < PPT; ++k) {
                 const int64_t t = t0 + k * kChunk + 2 * tid;
                 if (VEC2) {
-                    if (t < n) *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
+                    if (t < a.n_store) *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
                 } else {
-                    if (t < n) orow[t] = acc[k][0];
-                    if (t + 1 < n) orow[t + 1] = acc[k][1];
+                    if (t < a.n_store) orow[t] = acc[k][0];
+                    if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
                 }
             }
         } else {
-            __syncthreads();  // every lane has finished reading R_j / W_j
+            lds_barrier();  // every lane has finished reading R_j / W_j
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
-                if (act[k]) {
+                if (wr[k]) {
                     double2 v = make_double2(acc[k][0], acc[k][1]);
                     if (MODE == kZeroPad) {
                         // samples right of the signal are zero at every level
