@@ -1,0 +1,103 @@
+package ai.prophetizo.wavelet.gpu;
+
+import java.lang.foreign.Arena;
+import java.lang.foreign.FunctionDescriptor;
+import java.lang.foreign.Linker;
+import java.lang.foreign.MemorySegment;
+import java.lang.foreign.SymbolLookup;
+import java.lang.invoke.MethodHandle;
+
+import static java.lang.foreign.ValueLayout.ADDRESS;
+import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
+import static java.lang.foreign.ValueLayout.JAVA_INT;
+import static java.lang.foreign.ValueLayout.JAVA_LONG;
+
+/**
+ * FFM (java.lang.foreign) downcall handles for libvwgpu.so, the C ABI declared in include/vwgpu.h.
+ * No JNI shim: every handle is a direct downcall over off-heap MemorySegments.  Requires
+ * {@code --enable-native-access=ALL-UNNAMED} (or the module name) on Java 22+.
+ *
+ * <p>NOTE: written for Java 23 against the header; the build image of the GPU library has no JDK, so this
+ * file has not been compiled there.
+ */
+public final class VwGpuNative {
+    private static final Linker LINKER = Linker.nativeLinker();
+    private static final SymbolLookup LIB =
+        SymbolLookup.libraryLookup(System.getProperty("vectorwave.gpu.library", "libvwgpu.so"), Arena.global());
+
+    // status codes (vw_status)
+    public static final int VW_OK = 0, VW_E_NULL = 1, VW_E_NONFINITE = 3, VW_E_NOT_POSITIVE = 4, VW_E_TOO_LARGE = 5,
+        VW_E_EMPTY = 6, VW_E_LENGTH_MISMATCH = 7, VW_E_BOUNDARY = 103, VW_E_LEVEL = 104, VW_E_NO_DEVICE = 900;
+    // flags
+    public static final int FLAG_CHECK_FINITE = 1, FLAG_SYMMETRIC_BATCH_VARIANT = 2, FLAG_NO_LEVEL_CHECK = 4,
+        FLAG_SINGLE_LEVEL = 8;
+
+    private static MethodHandle h(String name, FunctionDescriptor fd) {
+        return LINKER.downcallHandle(LIB.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), fd);
+    }
+
+    static final MethodHandle VW_INIT = h("vw_init", FunctionDescriptor.of(JAVA_INT, JAVA_INT, ADDRESS));
+    static final MethodHandle VW_DESTROY = h("vw_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+    static final MethodHandle VW_LAST_ERROR = h("vw_last_error", FunctionDescriptor.of(ADDRESS, ADDRESS));
+    static final MethodHandle VW_PERFORMANCE_INFO = h("vw_performance_info", FunctionDescriptor.of(ADDRESS, ADDRESS));
+    static final MethodHandle VW_MAX_LEVELS = h("vw_max_levels", FunctionDescriptor.of(JAVA_INT, JAVA_LONG, JAVA_INT));
+
+    // int32 vw_modwt_forward_batch(ctx, x, b, n, levels, h, lh, g, lg, boundary, flags, coeffs, first_bad)
+    static final MethodHandle VW_FORWARD = h("vw_modwt_forward_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+    // int32 vw_modwt_inverse_batch(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, flags, x, first_bad)
+    static final MethodHandle VW_INVERSE = h("vw_modwt_inverse_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+    // int32 vw_modwt_inverse_bands_batch(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, band_mask, x)
+    static final MethodHandle VW_INVERSE_BANDS = h("vw_modwt_inverse_bands_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS));
+    // int32 vw_swt_denoise_batch(ctx, x, b, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold,
+    //                            sqrt_2_ln_n, soft, y, thresholds_out)
+    static final MethodHandle VW_DENOISE = h("vw_swt_denoise_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_DOUBLE, JAVA_DOUBLE, JAVA_INT, ADDRESS,
+            ADDRESS));
+    // int32 vw_swt_universal_threshold_batch(ctx, coeffs, b, n, levels, sqrt_2_ln_n, thresholds)
+    static final MethodHandle VW_UNIVERSAL_THRESHOLD = h("vw_swt_universal_threshold_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_DOUBLE, ADDRESS));
+    // int32 vw_threshold(ctx, in, count, threshold, soft, out)
+    static final MethodHandle VW_THRESHOLD = h("vw_threshold",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_DOUBLE, JAVA_INT, ADDRESS));
+    // int32 vw_modwt_convolve_batch(ctx, x, b, n, filter, filter_len, level, boundary, out)
+    static final MethodHandle VW_CONVOLVE = h("vw_modwt_convolve_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT,
+            ADDRESS));
+    // int32 vw_first_non_finite(ctx, x, count, first_bad)
+    static final MethodHandle VW_FIRST_NON_FINITE = h("vw_first_non_finite",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+
+    private VwGpuNative() {}
+
+    /** Opens a context on a HIP device; the returned segment is the opaque vw_ctx*. */
+    public static MemorySegment init(int device) {
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment out = a.allocate(ADDRESS);
+            int st = (int) VW_INIT.invokeExact(device, out);
+            if (st != VW_OK) {
+                throw new IllegalStateException("vw_init failed with status " + st + ": no usable HIP device");
+            }
+            return out.get(ADDRESS, 0);
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    public static String lastError(MemorySegment ctx) {
+        try {
+            MemorySegment p = (MemorySegment) VW_LAST_ERROR.invokeExact(ctx);
+            return p.reinterpret(512).getString(0);
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+}

@@ -1,0 +1,100 @@
+"""Frozen golden vectors (tests/golden/, made by tools/make_golden.py).
+
+CPU: the oracle must reproduce the committed vectors bit for bit (guards against compiler
+or flag drift in the checker itself) and satisfy the reference's closed-form KATs.
+GPU: the HIP path, through the C ABI, must reproduce the same committed vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from vectorwave_amd.wavelets import get_wavelet
+
+from util import assert_bits_equal
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    z = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    out = []
+    for key in z["_cases"]:
+        key = str(key)
+        wn, n, j, m = key.rsplit("_", 3)
+        out.append((key, wn.replace("_", "."), int(n[1:]), int(j[1:]), int(m[1:])))
+    return z, out
+
+
+def test_reference_kats_on_oracle():
+    k = json.load(open(os.path.join(GOLD, "reference_kats.json")))
+    c = o.modwt_forward_batch(np.array([k["haar_level1_approx"]["signal"]]), get_wavelet("haar"), 0)
+    np.testing.assert_allclose(c[0, 1], k["haar_level1_approx"]["approx"], rtol=0, atol=k["haar_level1_approx"]["tol"])
+    for name, fn in (("circular_06_04", o.circular_convolve), ("zero_pad_06_04", o.zero_padding_convolve),
+                     ("manual_circular", o.circular_convolve)):
+        e = k[name]
+        np.testing.assert_allclose(fn(e["signal"], e["filter"]), e["expected"], rtol=0, atol=e["tol"])
+    e = k["level2_dilation"]
+    np.testing.assert_allclose(o.circular_convolve_level(e["signal"], e["filter"], e["level"])[:2],
+                               e["expected_first_two"], rtol=0, atol=e["tol"])
+    e = k["time_reversed_haar"]
+    np.testing.assert_allclose(o.circular_convolve(e["signal"], e["filter"])[:2], e["expected_first_two"], rtol=0,
+                               atol=e["tol"])
+    for n, l, want in k["max_levels"]["cases"]:
+        assert o.max_levels(n, l) == want
+
+
+def test_oracle_reproduces_golden_vectors():
+    z, cases = _cases()
+    assert len(cases) == 30
+    for key, wn, n, j, mode in cases:
+        w = get_wavelet(wn)
+        x = z[key + "_x"]
+        st, c = o.decompose_batch(x, w, j, mode)
+        assert st == 0
+        assert_bits_equal(c, z[key + "_coeffs"], key + " coeffs")
+        assert_bits_equal(o.reconstruct_batch(c, w, mode), z[key + "_recon"], key + " recon")
+        if mode != 2:
+            assert_bits_equal(o.swt_denoise_batch(x, w, j, -1.0, True, mode)[1], z[key + "_denoise_soft"], key + " denoise")
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_vectors(ctx):
+    from util import gpu_denoise, gpu_forward, gpu_inverse
+    z, cases = _cases()
+    for key, wn, n, j, mode in cases:
+        x = np.ascontiguousarray(z[key + "_x"])
+        st, c, _ = gpu_forward(ctx, x, wn, j, mode)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(c, z[key + "_coeffs"], key + " coeffs")
+        st, r, _ = gpu_inverse(ctx, np.ascontiguousarray(z[key + "_coeffs"]), wn, mode)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(r, z[key + "_recon"], key + " recon")
+        if mode != 2:
+            st, y, thr = gpu_denoise(ctx, x, wn, j, mode, -1.0, True)
+            assert st == 0, ctx.last_error()
+            assert_bits_equal(y, z[key + "_denoise_soft"], key + " denoise")
+            assert_bits_equal(thr, z[key + "_thr"], key + " thresholds")
+
+
+@pytest.mark.gpu
+def test_gpu_reference_kats(ctx):
+    from vectorwave_amd import BoundaryMode, MODWTTransform, MultiLevelMODWTTransform, WaveletOperations as W
+    k = json.load(open(os.path.join(GOLD, "reference_kats.json")))
+    e = k["haar_level1_approx"]
+    r = MODWTTransform("haar", BoundaryMode.PERIODIC, ctx).forward(e["signal"])
+    np.testing.assert_allclose(r.approximationCoeffs(), e["approx"], rtol=0, atol=e["tol"])
+    e = k["circular_06_04"]
+    np.testing.assert_allclose(W.circularConvolveMODWT(e["signal"], e["filter"], None, ctx), e["expected"], rtol=0, atol=e["tol"])
+    e = k["zero_pad_06_04"]
+    np.testing.assert_allclose(W.zeroPaddingConvolveMODWT(e["signal"], e["filter"], None, ctx), e["expected"], rtol=0, atol=e["tol"])
+    e = k["manual_circular"]
+    np.testing.assert_allclose(W.circularConvolveMODWT(e["signal"], e["filter"], None, ctx), e["expected"], rtol=0, atol=e["tol"])
+    e = k["level2_dilation"]
+    np.testing.assert_allclose(W.circularConvolveMODWTLevel(e["signal"], e["filter"], None, e["level"], ctx)[:2],
+                               e["expected_first_two"], rtol=0, atol=e["tol"])
+    e = k["time_reversed_haar"]
+    np.testing.assert_allclose(W.circularConvolveMODWT(e["signal"], e["filter"], None, ctx)[:2], e["expected_first_two"], rtol=0, atol=e["tol"])
+    t = MultiLevelMODWTTransform("haar", BoundaryMode.PERIODIC, ctx)
+    assert t.getMaximumLevels(10000) == 9 and MultiLevelMODWTTransform.getMaxDecompositionLevels() == 10

@@ -1,0 +1,226 @@
+"""The host mirror of the reference API on the GPU: the reference's own unit tests for
+MODWTTransform / MultiLevelMODWTTransform / VectorWaveSwtAdapter restated against
+vectorwave_amd (reference test file:line in each comment; paths under
+src/test/java/ai/prophetizo/wavelet/)."""
+import math
+
+import numpy as np
+import pytest
+
+from vectorwave_amd import (BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult,
+                            MODWTTransform, MultiLevelMODWTTransform, VectorWaveSwtAdapter, get_wavelet)
+
+from util import signals
+
+pytestmark = pytest.mark.gpu
+PER, ZP, SYM = BoundaryMode.PERIODIC, BoundaryMode.ZERO_PADDING, BoundaryMode.SYMMETRIC
+
+
+def test_constructor_validation(ctx):
+    # modwt/MODWTTransformTest.java:29-42
+    with pytest.raises(TypeError):
+        MODWTTransform(None, PER, ctx)
+    with pytest.raises(TypeError):
+        MODWTTransform("haar", None, ctx)
+    with pytest.raises(InvalidArgumentException) as e:
+        MODWTTransform("haar", 5, ctx)
+    assert e.value.getErrorCode() == "CFG_003"
+    for m in (PER, ZP, SYM):
+        MODWTTransform("haar", m, ctx)
+
+
+@pytest.mark.parametrize("n", [8, 5, 1])
+def test_single_level_perfect_reconstruction(ctx, n):
+    # modwt/MODWTTransformTest.java:70-128
+    t = MODWTTransform("haar", PER, ctx)
+    x = signals(1, n, seed=n)[0]
+    r = t.forward(x)
+    assert r.getSignalLength() == n and r.isValid()
+    np.testing.assert_allclose(t.inverse(r), x, rtol=0, atol=1e-12)
+
+
+def test_invalid_signals(ctx):
+    # modwt/MODWTTransformTest.java:131-154
+    t = MODWTTransform("haar", PER, ctx)
+    with pytest.raises(TypeError):
+        t.forward(None)
+    with pytest.raises(InvalidSignalException) as e:
+        t.forward([])
+    assert e.value.getErrorCode() == "VAL_006"
+    for bad in (np.nan, np.inf, -np.inf):
+        with pytest.raises(InvalidSignalException) as e:
+            t.forward([1.0, bad, 3.0])
+        assert e.value.getErrorCode() == "VAL_003"
+    with pytest.raises(TypeError):
+        t.inverse(None)
+
+
+def test_symmetric_and_zero_padding_bounded(ctx):
+    # modwt/MODWTTransformTest.java:85-100; MultiLevelMODWTTransformTest.java:74-88
+    x = np.arange(1.0, 9.0)
+    t = MODWTTransform("haar", SYM, ctx)
+    assert np.abs(t.inverse(t.forward(x)) - x).max() < 1.1 * 8
+    m = MultiLevelMODWTTransform("haar", SYM, ctx)
+    assert np.abs(m.reconstruct(m.decompose(x, 2)) - x).max() < 3.1 * 8
+    z = MODWTTransform("haar", ZP, ctx)
+    r = z.inverse(z.forward(x))
+    np.testing.assert_allclose(r[1:-1], x[1:-1], atol=1e-10)
+
+
+@pytest.mark.parametrize("wn,n,j", [("haar", 8, 3), ("haar", 7, 2), ("db4", 32, 3), ("haar", 16, None),
+                                    ("haar", 100, None), ("haar", 1000, None), ("haar", 4, None), ("db4", 1000, 3)])
+def test_multilevel_reconstruction(ctx, wn, n, j):
+    # modwt/MultiLevelMODWTTransformTest.java:43-71, :169-200, :235-251; swt/SWTOptimizationTest.java:66-80
+    t = MultiLevelMODWTTransform(wn, PER, ctx)
+    x = signals(1, n, seed=n)[0]
+    res = t.decompose(x) if j is None else t.decompose(x, j)
+    assert res.getSignalLength() == n
+    assert res.getLevels() == (t.getMaximumLevels(n) if j is None else j)
+    np.testing.assert_allclose(t.reconstruct(res), x, rtol=0, atol=1e-10)
+
+
+def test_multilevel_level_validation(ctx):
+    # modwt/MultiLevelMODWTTransformTest.java:203-218, :254-291
+    t = MultiLevelMODWTTransform("haar", PER, ctx)
+    x = signals(1, 64)[0]
+    for bad in (0, 20, -1):
+        with pytest.raises(InvalidArgumentException) as e:
+            t.decompose(x, bad)
+        assert e.value.getErrorCode() == "CFG_004"
+    assert MultiLevelMODWTTransform.getMaxDecompositionLevels() == 10
+    assert t.getMaximumLevels(10000) == 9
+    # finiteness is validated before the level count (modwt/MultiLevelMODWTTransform.java:216-244)
+    xb = x.copy()
+    xb[3] = np.nan
+    with pytest.raises(InvalidSignalException):
+        t.decompose(xb, 20)
+    with pytest.raises(InvalidSignalException):
+        t.decompose([], 1)
+
+
+def test_partial_reconstructions(ctx):
+    # modwt/MultiLevelMODWTTransform.java:385-468 semantics
+    t = MultiLevelMODWTTransform("db4", PER, ctx)
+    x = signals(1, 256, seed=3)[0]
+    res = t.decompose(x, 4)
+    full = t.reconstruct(res)
+    np.testing.assert_allclose(t.reconstructFromLevel(res, 1), full, atol=1e-12)
+    bands = sum(t.reconstructLevels(res, k, k) for k in range(1, 4)) + t.reconstructLevels(res, 4, 4)
+    np.testing.assert_allclose(bands, x, atol=1e-8)
+    with pytest.raises(InvalidArgumentException):
+        t.reconstructLevels(res, 0, 2)
+    with pytest.raises(InvalidArgumentException):
+        t.reconstructFromLevel(res, 5)
+
+
+def test_batch_equals_per_signal(ctx):
+    # modwt/BatchSIMDMODWTTest.java:55-182: batch == per-signal forward at 1e-10 (here: exact);
+    # integration/SimplifiedAPIWorkflowTest.java:103-144: 32 x 777 DB4 forwardBatch/inverseBatch
+    for wn, b, n in (("haar", 8, 16), ("db4", 16, 64), ("db4", 7, 64), ("db4", 32, 777), ("db4", 8, 128)):
+        t = MODWTTransform(wn, PER, ctx)
+        xs = signals(b, n, seed=b + n)
+        batch = t.forwardBatch(list(xs))
+        assert len(batch) == b
+        for i in range(b):
+            one = t.forward(xs[i])
+            assert np.array_equal(batch[i].approximationCoeffs(), one.approximationCoeffs())
+            assert np.array_equal(batch[i].detailCoeffs(), one.detailCoeffs())
+        back = t.inverseBatch(batch)
+        for i in range(b):
+            np.testing.assert_allclose(back[i], xs[i], atol=1e-10)
+    # ragged batch falls back to per-signal calls
+    t = MODWTTransform("db4", PER, ctx)
+    rag = t.forwardBatch([np.ones(10), np.ones(20), np.ones(30)])
+    assert [r.getSignalLength() for r in rag] == [10, 20, 30]
+    assert t.forwardBatch([]) == []
+    with pytest.raises(TypeError):
+        t.forwardBatch(None)
+    # forwardBatchOptimized skips input validation; the NaN surfaces when results are built
+    xs = signals(4, 64)
+    xs[2, 7] = np.nan
+    with pytest.raises(InvalidSignalException):
+        t.forwardBatch(list(xs))
+
+
+def test_swt_adapter(ctx):
+    # swt/VectorWaveSwtAdapterTest.java:23-42 (DB4 J=3 N=64 PR 1e-10)
+    a = VectorWaveSwtAdapter("db4", ctx=ctx)
+    assert a.getBoundaryMode() == PER
+    x = signals(1, 64, seed=64)[0]
+    res = a.forward(x, 3)
+    np.testing.assert_allclose(a.inverse(res), x, atol=1e-10)
+    # :79-104 hard threshold: |c| <= thr -> 0, others unchanged
+    before = res.getDetailCoeffsAtLevel(1)
+    a.applyThreshold(res, 1, 0.05, False)
+    after = res.getDetailCoeffsAtLevel(1)
+    assert np.all(after[np.abs(before) <= 0.05] == 0.0)
+    assert np.array_equal(after[np.abs(before) > 0.05], before[np.abs(before) > 0.05])
+    # soft on the approximation (level 0)
+    ab = res.getApproximationCoeffs()
+    a.applyThreshold(res, 0, 0.1, True)
+    aa = res.getApproximationCoeffs()
+    np.testing.assert_array_equal(aa, np.where(np.abs(ab) > 0.1, np.sign(ab) * (np.abs(ab) - 0.1), 0.0))
+
+
+def test_swt_universal_threshold_and_denoise(ctx):
+    # swt/VectorWaveSwtAdapterTest.java:243-268: DB4 J=4 N=256, noise sigma=0.1: zeroes some, keeps some
+    a = VectorWaveSwtAdapter("db4", PER, ctx)
+    n = 256
+    t = np.arange(n)
+    rng = np.random.default_rng(42)
+    x = np.sin(2 * np.pi * t / 32.0) + 0.1 * rng.standard_normal(n)
+    res = a.forward(x, 4)
+    d1 = res.getDetailCoeffsAtLevel(1)
+    thr = a.universalThreshold(res)
+    srt = np.sort(np.abs(d1))
+    assert thr == ((srt[n // 2 - 1] + srt[n // 2]) / 2.0 / 0.6745) * math.sqrt(2 * math.log(n))
+    a.applyUniversalThreshold(res, True)
+    nz = sum(int((res.getDetailCoeffsAtLevel(k) == 0).sum()) for k in range(1, 5))
+    kept = sum(int((res.getDetailCoeffsAtLevel(k) != 0).sum()) for k in range(1, 5))
+    assert nz > 0 and kept > 0
+    # :336-356 denoise(-1) == denoise(-999); step-by-step == one-call
+    y1 = a.denoise(x, 4, -1, True)
+    y2 = a.denoise(x, 4, -999, True)
+    assert np.array_equal(y1, y2)
+    assert np.array_equal(a.inverse(res), y1)
+    # :315-333 PERIODIC round trip RMSE < 1e-8, other modes < 1.0
+    # (the reference's signal generator, :423-430, Haar J=2 on 64 samples)
+    i64 = np.arange(64)
+    s64 = np.sin(2 * np.pi * i64 / 16.0) + 0.5 * np.cos(4 * np.pi * i64 / 16.0)
+    for mode, tol in ((PER, 1e-8), (ZP, 1.0), (SYM, 1.0)):
+        am = VectorWaveSwtAdapter("haar", mode, ctx)
+        r = am.inverse(am.forward(s64, 2))
+        assert math.sqrt(np.mean((r - s64) ** 2)) < tol
+    # :205-217 sum of extractLevel(0..3) == signal at 1e-8
+    total = sum(a.extractLevel(x, 3, k) for k in range(4))
+    np.testing.assert_allclose(total, x, atol=1e-8)
+    # batch denoise == per-signal denoise
+    xs = signals(5, 480, seed=9)
+    yb = a.denoiseBatch(xs, 4)
+    for i in range(5):
+        assert np.array_equal(yb[i], a.denoise(xs[i], 4))
+
+
+def test_result_containers(ctx):
+    # swt/VectorWaveSwtAdapterTest.java:399-419: NaN -> isValid() == false
+    t = MultiLevelMODWTTransform("haar", PER, ctx)
+    res = t.decomposeMutable(signals(1, 32)[0], 2)
+    assert res.isValid()
+    res.getMutableDetailCoeffs(1)[3] = np.nan
+    assert not res.isValid()
+    res.getMutableDetailCoeffs(1)[3] = 0.0
+    # getters clone, getMutable* alias
+    d = res.getDetailCoeffsAtLevel(1)
+    d[0] = 123.0
+    assert res.getDetailCoeffsAtLevel(1)[0] != 123.0
+    with pytest.raises(ValueError):
+        res.getDetailCoeffsAtLevel(3)
+    e = res.getRelativeEnergyDistribution()
+    assert abs(e.sum() - 1.0) < 1e-12 and e.size == 3
+    imm = res.toImmutable()
+    ei = imm.getRelativeEnergyDistribution()
+    assert abs(ei[0] - e[2]) < 1e-15  # immutable: [approx, d1..dJ]; mutable: [d1..dJ, approx]
+    with pytest.raises(InvalidSignalException):
+        MODWTResult.create([1.0, np.nan], [0.0, 0.0])
+    with pytest.raises(ValueError):
+        MODWTResult.create([1.0], [0.0, 0.0])

@@ -76,3 +76,64 @@ def assert_bits_equal(a, b, what=""):
         first = tuple(idx[0])
         raise AssertionError("%s: %d of %d elements differ; first at %s: got %r (%s) want %r (%s)" % (
             what, idx.shape[0], a.size, first, a[first], float(a[first]).hex(), b[first], float(b[first]).hex()))
+
+
+# ---- device-resident helpers (torch tensors on the GPU, *_dev entry points) -------------------
+
+def dev_forward(ctx, x_t, wname, levels, boundary, flags=0, out=None):
+    import torch
+    w = get_wavelet(wname)
+    h, g = _t(w.dec_lo), _t(w.dec_hi)
+    b, n = x_t.shape
+    if out is None:
+        out = torch.empty((b, levels + 1, n), dtype=torch.float64, device=x_t.device)
+    sp = C.c_void_p(torch.cuda.current_stream(x_t.device).cuda_stream)
+    st = ctx.lib.vw_modwt_forward_batch_dev(ctx.handle, C.c_void_p(x_t.data_ptr()), b, n, levels, _dp(h), h.size,
+                                            _dp(g), g.size, boundary, flags, C.c_void_p(out.data_ptr()), None, sp)
+    assert st == 0, ctx.last_error()
+    return out
+
+
+def dev_inverse(ctx, c_t, wname, boundary, flags=0, out=None):
+    import torch
+    w = get_wavelet(wname)
+    hr, gr = _t(w.rec_lo), _t(w.rec_hi)
+    b, jp1, n = c_t.shape
+    if out is None:
+        out = torch.empty((b, n), dtype=torch.float64, device=c_t.device)
+    sp = C.c_void_p(torch.cuda.current_stream(c_t.device).cuda_stream)
+    st = ctx.lib.vw_modwt_inverse_batch_dev(ctx.handle, C.c_void_p(c_t.data_ptr()), b, n, jp1 - 1, _dp(hr), hr.size,
+                                            _dp(gr), gr.size, boundary, flags, C.c_void_p(out.data_ptr()), None, sp)
+    assert st == 0, ctx.last_error()
+    return out
+
+
+def dev_denoise(ctx, x_t, wname, levels, boundary, threshold, soft, out=None):
+    import torch
+    w = get_wavelet(wname)
+    h, g, hr, gr = _t(w.dec_lo), _t(w.dec_hi), _t(w.rec_lo), _t(w.rec_hi)
+    b, n = x_t.shape
+    if out is None:
+        out = torch.empty((b, n), dtype=torch.float64, device=x_t.device)
+    thr = torch.empty((b,), dtype=torch.float64, device=x_t.device)
+    sp = C.c_void_p(torch.cuda.current_stream(x_t.device).cuda_stream)
+    st = ctx.lib.vw_swt_denoise_batch_dev(ctx.handle, C.c_void_p(x_t.data_ptr()), b, n, levels, _dp(h), h.size, _dp(g),
+                                          g.size, _dp(hr), hr.size, _dp(gr), gr.size, boundary, float(threshold),
+                                          math.sqrt(2 * math.log(n)), 1 if soft else 0, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(thr.data_ptr()), None, 0, sp)
+    assert st == 0, ctx.last_error()
+    return out, thr
+
+
+def dev_signals(b, n, seed=42, device="cuda:0", noise=0.1):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64, device=device)
+    base = torch.sin(2 * math.pi * t / 32.0) + 0.5 * torch.sin(2 * math.pi * t / 64.0)
+    x = torch.empty((b, n), dtype=torch.float64, device=device)
+    chunk = max(1, (256 << 20) // (n * 8))
+    for r0 in range(0, b, chunk):
+        r1 = min(b, r0 + chunk)
+        x[r0:r1] = base[None] + noise * torch.randn((r1 - r0, n), dtype=torch.float64, device=device, generator=g)
+    return x

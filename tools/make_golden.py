@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Freeze golden vectors for the MODWT/SWT path under tests/golden/.
+
+The reference is Java and cannot run in the build image, and its tests hold no
+numeric golden files -- only closed-form known answers.  So two fixtures are kept:
+
+  reference_kats.json   the closed-form known-answer vectors transcribed (as data:
+                        inputs and expected outputs) from the reference's unit tests,
+                        with the test file:line of each
+  oracle_vectors.npz    seeded inputs and the outputs of the CPU oracle (the C restatement
+                        of the reference's algorithm, itself pinned by the KATs) for every
+                        (wavelet, boundary, N, J) case listed below: coefficient blocks,
+                        reconstructions, denoise outputs and thresholds
+
+Run from the repo root:  python tools/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import oracle as o  # noqa: E402
+from util import signals  # noqa: E402
+from vectorwave_amd.wavelets import get_wavelet  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+KATS = {
+    "_comment": "Closed-form known answers held by the reference's unit tests (paths under "
+                "src/test/java/ai/prophetizo/wavelet/). Data only.",
+    "haar_level1_approx": {
+        "source": "modwt/MODWTPercivalWaldenValidationTest.java:73-82",
+        "wavelet": "haar", "boundary": 0, "signal": [1.0, 2.0, 3.0, 4.0],
+        "approx": [2.5, 1.5, 2.5, 3.5], "tol": 1e-12},
+    "circular_06_04": {
+        "source": "internal/ScalarOpsTest.java:225-240",
+        "signal": [1.0, 2.0, 3.0, 4.0], "filter": [0.6, 0.4], "boundary": 0,
+        "expected": [2.2, 1.6, 2.6, 3.6], "tol": 1e-10},
+    "zero_pad_06_04": {
+        "source": "internal/ScalarOpsTest.java:262-274",
+        "signal": [1.0, 2.0, 3.0, 4.0], "filter": [0.6, 0.4], "boundary": 1,
+        "expected": [0.6, 1.6, 2.6, 3.6], "tol": 1e-10},
+    "level2_dilation": {
+        "source": "internal/ScalarOpsTest.java:245-258",
+        "signal": [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], "filter": [0.7, 0.3], "level": 2,
+        "expected_first_two": [2.8, 3.8], "tol": 1e-10},
+    "time_reversed_haar": {
+        "source": "modwt/TimeReversedFilterTest.java:20-50",
+        "signal": [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0], "filter": [0.7071067811865475, 0.7071067811865475],
+        "expected_first_two": [0.7071067811865475 * 1 + 0.7071067811865475 * 8,
+                               0.7071067811865475 * 2 + 0.7071067811865475 * 1], "tol": 1e-10},
+    "manual_circular": {
+        "source": "modwt/MODWTMathematicalValidationTest.java:296-316",
+        "signal": [1.0, 4.0, 2.0, 8.0], "filter": [0.5, -0.5], "boundary": 0,
+        "expected": [-3.5, 1.5, -1.0, 3.0], "tol": 1e-12},
+    "max_levels": {
+        "source": "modwt/MultiLevelMODWTTransformTest.java:254-291",
+        "cases": [[10000, 2, 9], [8, 8, 0], [9, 8, 1]]},
+    "soa_layout": {
+        "source": "modwt/BatchSIMDMODWTTest.java:28-52",
+        "rows": [[1.0, 2.0, 3.0, 4.0], [5.0, 6.0, 7.0, 8.0], [9.0, 10.0, 11.0, 12.0]],
+        "soa": [1.0, 5.0, 9.0, 2.0, 6.0, 10.0, 3.0, 7.0, 11.0, 4.0, 8.0, 12.0]},
+}
+
+CASES = [  # wavelet, N, J
+    ("haar", 64, 3), ("haar", 8, 3), ("db2", 64, 3), ("db4", 64, 3), ("db4", 301, 5), ("db4", 480, 4),
+    ("db10", 400, 4), ("sym8", 333, 4), ("coif3", 301, 4), ("bior4.4", 200, 4),
+]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "reference_kats.json"), "w") as f:
+        json.dump(KATS, f, indent=1)
+    arrays = {}
+    names = []
+    for wn, n, j in CASES:
+        w = get_wavelet(wn)
+        x = signals(2, n, seed=1000 + n + j)
+        for mode in (0, 1, 2):
+            key = "%s_N%d_J%d_m%d" % (wn.replace(".", "_"), n, j, mode)
+            st, c = o.decompose_batch(x, w, j, mode)
+            assert st == 0, key
+            arrays[key + "_x"] = x
+            arrays[key + "_coeffs"] = c
+            arrays[key + "_recon"] = o.reconstruct_batch(c, w, mode)
+            if mode != 2:
+                st, y = o.swt_denoise_batch(x, w, j, -1.0, True, mode)
+                arrays[key + "_denoise_soft"] = y
+                arrays[key + "_thr"] = np.array([o.universal_threshold(c[i, 0]) for i in range(2)])
+            names.append(key)
+        c1 = o.modwt_forward_batch(x, w, 0)
+        arrays["%s_N%d_single_coeffs" % (wn.replace(".", "_"), n)] = c1
+    arrays["_cases"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "oracle_vectors.npz"), **arrays)
+    sz = os.path.getsize(os.path.join(OUT, "oracle_vectors.npz"))
+    print("wrote %d cases, %.1f KiB" % (len(names), sz / 1024))
+
+
+if __name__ == "__main__":
+    main()
