@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--levels", type=int, default=6)
     ap.add_argument("--wavelet", default="db4")
     ap.add_argument("--boundary", type=int, default=0)
+    ap.add_argument("--arith", choices=["exact", "fma"], default="exact",
+                    help="exact: the reference's arithmetic, bit parity (default); fma: VW_FLAG_FMA")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the secondary run in the other arithmetic mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -99,9 +102,12 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
 
+    mode_flags = {"exact": 0, "fma": N.VW_FLAG_FMA}
+    flags = [mode_flags[args.arith]]
+
     def fwd():
         st = lib.vw_modwt_forward_batch_dev(ctx.handle, C.c_void_p(x.data_ptr()), rows, n, J, h.ctypes.data_as(dp),
-                                            h.size, g.ctypes.data_as(dp), g.size, args.boundary, 0,
+                                            h.size, g.ctypes.data_as(dp), g.size, args.boundary, flags[0],
                                             C.c_void_p(coeffs.data_ptr()), None, sp)
         if st != 0:
             raise RuntimeError("forward failed: %d %s" % (st, ctx.last_error()))
@@ -109,7 +115,7 @@ def main():
     def inv():
         st = lib.vw_modwt_inverse_batch_dev(ctx.handle, C.c_void_p(coeffs.data_ptr()), rows, n, J,
                                             hr.ctypes.data_as(dp), hr.size, gr.ctypes.data_as(dp), gr.size,
-                                            args.boundary, 0, C.c_void_p(xr.data_ptr()), None, sp)
+                                            args.boundary, flags[0], C.c_void_p(xr.data_ptr()), None, sp)
         if st != 0:
             raise RuntimeError("inverse failed: %d %s" % (st, ctx.last_error()))
 
@@ -142,20 +148,56 @@ def main():
     fwd_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
     inv_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
 
-    # ---- sanity: perfect reconstruction at full size, bit parity on a few rows ------------
+    # ---- sanity: perfect reconstruction at full size, parity with the oracle on a few rows ------------
     err = float((xr[: min(rows, 4096)] - x[: min(rows, 4096)]).abs().max().item())
     verified = None
+    max_dev = None
     cpu = None
     if rank == 0:
         from oracle import oracle as o
         xs = x[:2].cpu().numpy()
         st, want = o.decompose_batch(xs, w, J, args.boundary)
         got = coeffs[:2].cpu().numpy()
-        verified = bool(st == 0 and np.array_equal(got.view(np.uint64), want.view(np.uint64)))
         wantx = o.reconstruct_batch(want, w, args.boundary)
-        verified = verified and bool(np.array_equal(xr[:2].cpu().numpy().view(np.uint64), wantx.view(np.uint64)))
+        gotx = xr[:2].cpu().numpy()
+        verified = bool(st == 0 and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+                        and np.array_equal(gotx.view(np.uint64), wantx.view(np.uint64)))
+        # north-star tolerance: |gpu - ref| <= 1e-12 * max(|ref|, max|x|)
+        scale = float(np.abs(xs).max())
+        max_dev = float(max((np.abs(got - want) / np.maximum(np.abs(want), scale)).max(),
+                            (np.abs(gotx - wantx) / np.maximum(np.abs(wantx), scale)).max()))
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(o, w, J, n, args)
+
+    # ---- secondary run in the other arithmetic mode (reported beside the headline, never as `value`) ----
+    alt = None
+    if not args.no_alt_mode:
+        other = "fma" if args.arith == "exact" else "exact"
+        flags[0] = mode_flags[other]
+        for _ in range(max(1, args.warmup)):
+            fwd()
+            inv()
+        barrier()
+        ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        nrep = max(3, args.steps // 2)
+        ev2[0].record(stream)
+        for _ in range(nrep):
+            fwd()
+        ev2[1].record(stream)
+        for _ in range(nrep):
+            inv()
+        ev2[2].record(stream)
+        torch.cuda.synchronize(dev)
+        f2, i2 = ev2[0].elapsed_time(ev2[1]) / nrep, ev2[1].elapsed_time(ev2[2]) / nrep
+        alt = {"arith": other, "forward_ms": round(f2, 4), "inverse_ms": round(i2, 4),
+               "Gsamples_per_s_per_gpu": round(rows * n / ((f2 + i2) * 1e-3) / 1e9, 4),
+               "pct_of_hbm_roofline": round(100.0 * rows * n / ((f2 + i2) * 1e-3) / 1e9 * 16 * (J + 2) / HBM_PEAK_GBS, 2)}
+        if rank == 0:
+            got2 = coeffs[:2].cpu().numpy()
+            gotx2 = xr[:2].cpu().numpy()
+            alt["max_rel_dev_vs_oracle"] = float(max((np.abs(got2 - want) / np.maximum(np.abs(want), scale)).max(),
+                                                     (np.abs(gotx2 - wantx) / np.maximum(np.abs(wantx), scale)).max()))
+        flags[0] = mode_flags[args.arith]
 
     samples = rows * n * args.steps * world
     value = samples / elapsed / 1e9
@@ -194,8 +236,11 @@ def main():
         "pct_of_hbm_roofline": round(100.0 * value / world * 16 * (J + 2) / HBM_PEAK_GBS, 2),
         "forward_ms": round(fwd_ms, 4),
         "inverse_ms": round(inv_ms, 4),
+        "arith": args.arith,
         "max_reconstruction_error": err,
         "bit_exact_vs_oracle": verified,
+        "max_rel_dev_vs_oracle": max_dev,
+        "alt_mode": alt,
         "roofline": {
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

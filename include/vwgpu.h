@@ -92,7 +92,13 @@ enum {
      * signal truncated to its length (modwt/MultiLevelMODWTTransform.java:
      * 801-806, 628-636), SYMMETRIC inverse adding the low-pass and high-pass
      * products to the sum one after the other (:664-685). */
-    VW_FLAG_SINGLE_LEVEL = 8
+    VW_FLAG_SINGLE_LEVEL = 8,
+    /* Opt out of bit parity: let the tiled kernels fuse each multiply-add (one rounding per tap
+     * instead of two).  Half the fp64 instructions; every coefficient stays within
+     * 1e-12 * max(|ref|, max|x|) of the default arithmetic (measured ~1e-15), but is no longer
+     * bit-identical to the reference's scalar Java path.  Ignored by the one-level generic
+     * kernels (SYMMETRIC, truncated filters). */
+    VW_FLAG_FMA = 16
 };
 
 /* ---- context ----------------------------------------------------------- */

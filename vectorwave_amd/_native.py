@@ -32,6 +32,7 @@ VW_FLAG_CHECK_FINITE = 1
 VW_FLAG_SYMMETRIC_BATCH_VARIANT = 2
 VW_FLAG_NO_LEVEL_CHECK = 4
 VW_FLAG_SINGLE_LEVEL = 8
+VW_FLAG_FMA = 16
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)

@@ -187,7 +187,7 @@ static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileC
     int hpt = 0;
     for (int i = 0; i < ncfg; ++i) {
         const TileCfg& c = kCfgs[i];
-        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * (inverse ? 2 : 1);
+        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * 2;  // two buffers in both directions
         if (c.hpt < hpt_need || lds > static_cast<size_t>(lds_limit)) continue;
         if (hpt == 0 || c.hpt < hpt) hpt = c.hpt;
     }
@@ -196,7 +196,7 @@ static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileC
     int best = -1;
     for (int i = 0; i < ncfg; ++i) {
         const TileCfg& c = kCfgs[i];
-        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * (inverse ? 2 : 1);
+        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * 2;  // two buffers in both directions
         if (c.hpt != hpt || lds > static_cast<size_t>(lds_limit)) continue;
         if (best < 0) {
             best = i;
@@ -263,18 +263,29 @@ static hipError_t launch_tile(K kernel, const A& args, int64_t nblocks, size_t l
     return hipGetLastError();
 }
 
-#define VW_FWD_CASE(P, H)                                                                              \
-    if (cfg.ppt == P && cfg.hpt == H) {                                                                \
-        if (mode == kPeriodic)                                                                         \
-            return vec2 ? launch_tile(k_fwd_fused<P, H, kPeriodic, true>, a, nblocks, lds, stream)     \
-                        : launch_tile(k_fwd_fused<P, H, kPeriodic, false>, a, nblocks, lds, stream);   \
-        return vec2 ? launch_tile(k_fwd_fused<P, H, kZeroPad, true>, a, nblocks, lds, stream)          \
-                    : launch_tile(k_fwd_fused<P, H, kZeroPad, false>, a, nblocks, lds, stream);        \
-    }
+template <int P, int H, int MODE>
+static hipError_t launch_fwd_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile(k_fwd_fused<P, H, MODE, true, true>, a, nblocks, lds, stream)
+                         : launch_tile(k_fwd_fused<P, H, MODE, true, false>, a, nblocks, lds, stream);
+    return fma ? launch_tile(k_fwd_fused<P, H, MODE, false, true>, a, nblocks, lds, stream)
+               : launch_tile(k_fwd_fused<P, H, MODE, false, false>, a, nblocks, lds, stream);
+}
+template <int P, int H, int MODE>
+static hipError_t launch_inv_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile(k_inv_fused<P, H, MODE, true, true>, a, nblocks, lds, stream)
+                         : launch_tile(k_inv_fused<P, H, MODE, true, false>, a, nblocks, lds, stream);
+    return fma ? launch_tile(k_inv_fused<P, H, MODE, false, true>, a, nblocks, lds, stream)
+               : launch_tile(k_inv_fused<P, H, MODE, false, false>, a, nblocks, lds, stream);
+}
 
-static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, int64_t nblocks,
+#define VW_FWD_CASE(P, H)                                                                                    \
+    if (cfg.ppt == P && cfg.hpt == H)                                                                        \
+        return mode == kPeriodic ? launch_fwd_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
+                                 : launch_fwd_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+
+static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
                              hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8;
+    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8 * 2;
     VW_FWD_CASE(1, 1)
     VW_FWD_CASE(2, 1)
     VW_FWD_CASE(4, 1)
@@ -286,16 +297,12 @@ static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2,
     return hipErrorInvalidValue;
 }
 
-#define VW_INV_CASE(P, H)                                                                              \
-    if (cfg.ppt == P && cfg.hpt == H) {                                                                \
-        if (mode == kPeriodic)                                                                         \
-            return vec2 ? launch_tile(k_inv_fused<P, H, kPeriodic, true>, a, nblocks, lds, stream)     \
-                        : launch_tile(k_inv_fused<P, H, kPeriodic, false>, a, nblocks, lds, stream);   \
-        return vec2 ? launch_tile(k_inv_fused<P, H, kZeroPad, true>, a, nblocks, lds, stream)          \
-                    : launch_tile(k_inv_fused<P, H, kZeroPad, false>, a, nblocks, lds, stream);        \
-    }
+#define VW_INV_CASE(P, H)                                                                                    \
+    if (cfg.ppt == P && cfg.hpt == H)                                                                        \
+        return mode == kPeriodic ? launch_inv_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
+                                 : launch_inv_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
 
-static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, int64_t nblocks,
+static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
                              hipStream_t stream) {
     const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8 * 2;
     VW_INV_CASE(1, 1)
@@ -307,6 +314,19 @@ static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2,
     VW_INV_CASE(8, 4)
     VW_INV_CASE(8, 10)
     return hipErrorInvalidValue;
+}
+
+// VW_STAGGER="<blocks>,<unit>" overrides the start-up stagger (0,0 switches it off).
+static void stagger_params(int32_t* blocks, int32_t* unit) {
+    *blocks = 0;
+    *unit = 0;
+    if (const char* e = getenv("VW_STAGGER")) {
+        int b = 0, u = 0;
+        if (sscanf(e, "%d,%d", &b, &u) == 2) {
+            *blocks = b;
+            *unit = u;
+        }
+    }
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -446,6 +466,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
             }
+            stagger_params(&a.stagger_blocks, &a.stagger_unit);
             int64_t hn[kMaxLevels + 2] = {0};
             fwd_halo(st.lev0, st.lev1, lh, lg, hn);
             const int64_t halo = static_cast<int64_t>(st.cfg.hpt) * kChunk;
@@ -453,6 +474,8 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                 int64_t ps = halo - hn[j];
                 if (ps < 0) ps = 0;
                 a.pstart[j] = static_cast<int32_t>(ps & ~static_cast<int64_t>(1));
+                if (const char* dbg = getenv("VW_ABLATE"))
+                    if (strstr(dbg, "nohalo")) a.pstart[j] = static_cast<int32_t>(halo);
             }
             a.first_bad = first ? first_bad_cell : nullptr;
             a.taps = taps;
@@ -460,7 +483,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, nblocks, stream);
+            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
         } else {
             if (first && first_bad_cell != nullptr) {
@@ -682,11 +705,14 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = 0;
+                if (strstr(dbg, "nohalo"))
+                    for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
             }
+            stagger_params(&a.stagger_blocks, &a.stagger_unit);
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t er = launch_inv(a, st.cfg, boundary, vec2, nblocks, stream);
+            hipError_t er = launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
             if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));
         } else {
             if (first && first_bad_cell != nullptr)

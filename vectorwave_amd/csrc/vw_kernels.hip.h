@@ -47,6 +47,7 @@ struct FwdArgs {
     int64_t v_stride;
     int64_t n;
     int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
+    int32_t stagger_blocks, stagger_unit;  // see stagger_start
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels computed by this launch (inclusive)
@@ -66,6 +67,7 @@ struct InvArgs {
     int64_t rout_stride;
     int64_t n;
     int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
+    int32_t stagger_blocks, stagger_unit;  // see stagger_start
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
@@ -101,6 +103,17 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblk) {
 // completed" + s_barrier is all the tile hand-off between waves needs.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// All workgroups do identical work, so the first resident wave of them would otherwise stay phase
+// locked (everyone loads, then everyone computes, then everyone stores) and HBM and the VALUs would
+// take turns idling.  The first `count` workgroups therefore start after a pseudo-random fraction of
+// one tile time; later workgroups inherit the spread because they start when an earlier one ends.
+__device__ __forceinline__ void stagger_start(int count, int unit_sleeps) {
+    if (static_cast<int>(blockIdx.x) < count) {
+        const unsigned k = (static_cast<unsigned>(blockIdx.x) * 2654435761u) >> 29;  // 0..7
+        for (unsigned i = 0; i < k * static_cast<unsigned>(unit_sleeps); ++i) __builtin_amdgcn_s_sleep(64);
+    }
 }
 
 __device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n) {
@@ -152,7 +165,15 @@ __device__ __forceinline__ double apply_thr(double c, double thr, int mode) {
 // needed pair instead (its address is clamped, its result is not written back).
 // Per-lane predicates inside the tap loop would split every tap into
 // exec-masked blocks with their own LDS waits.
-template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI>
+// FMA = false is the reference's arithmetic (product and sum rounded separately: bit parity with the
+// Java scalar path).  FMA = true fuses each multiply-add (one rounding per tap instead of two): half
+// the fp64 instructions, results within ~1e-15 relative of the exact path, not bit-identical.
+template <bool FMA>
+__device__ __forceinline__ double mac(double acc, double x, double f) {
+    return FMA ? __builtin_fma(x, f, acc) : acc + x * f;
+}
+
+template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI, bool FMA, bool FIRST = false>
 __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&hbase)[HPT], int off, double flo,
                                         double fhi, double (&av)[PPT][2], double (&aw)[PPT][2],
                                         double (&ah)[HPT][2], double (&xp)[PPT], double (&xph)[HPT],
@@ -170,13 +191,15 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
+        // FIRST: the reference's `sum = 0.0; sum += x*f` -- the add of +0.0 is kept (it turns a -0.0
+        // product into +0.0), only the separate zero-initialisation of the accumulator is saved
         if (DO_LO) {
-            av[k][0] = av[k][0] + xt[k].x * flo;
-            av[k][1] = av[k][1] + xt[k].y * flo;
+            av[k][0] = mac<FMA>(FIRST ? 0.0 : av[k][0], xt[k].x, flo);
+            av[k][1] = mac<FMA>(FIRST ? 0.0 : av[k][1], xt[k].y, flo);
         }
         if (DO_HI) {
-            aw[k][0] = aw[k][0] + xt[k].x * fhi;
-            aw[k][1] = aw[k][1] + xt[k].y * fhi;
+            aw[k][0] = mac<FMA>(FIRST ? 0.0 : aw[k][0], xt[k].x, fhi);
+            aw[k][1] = mac<FMA>(FIRST ? 0.0 : aw[k][1], xt[k].y, fhi);
         }
     }
     if (DO_LO) {
@@ -193,14 +216,14 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
                     x0 = x.x;
                     x1 = x.y;
                 }
-                ah[c][0] = ah[c][0] + x0 * flo;
-                ah[c][1] = ah[c][1] + x1 * flo;
+                ah[c][0] = mac<FMA>(ah[c][0], x0, flo);
+                ah[c][1] = mac<FMA>(ah[c][1], x1, flo);
             }
         }
     }
 }
 
-template <int PPT, int HPT, bool S1>
+template <int PPT, int HPT, bool S1, bool FMA>
 __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int s, int tid,
                                           double (&av)[PPT][2], double (&aw)[PPT][2],
                                           double (&ah)[HPT][2], const int (&hbase)[HPT], const bool (&wact)[HPT]) {
@@ -221,35 +244,47 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
     int off = 0;
     int l = 0;
     double flo = a.taps.lo[0], fhi = a.taps.hi[0];
+    if (lmin > 0) {  // tap 0 defines the tile accumulators
+        const double flo_n = a.taps.lo[1], fhi_n = a.taps.hi[1];
+        fwd_tap<PPT, HPT, S1, true, true, FMA, true>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
+        off += sb;
+        flo = flo_n;
+        fhi = fhi_n;
+        l = 1;
+    }
     for (; l < lmin; ++l) {
         const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, true, true>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, true, FMA>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
         fhi = fhi_n;
     }
     for (; l < lh; ++l) {  // low-pass longer than high-pass
         const double flo_n = a.taps.lo[l + 1];
-        fwd_tap<PPT, HPT, S1, true, false>(lds, baseT, hbase, off, flo, 0.0, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, false, FMA>(lds, baseT, hbase, off, flo, 0.0, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
     }
     for (; l < lg; ++l) {  // high-pass longer than low-pass
         const double fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, false, true>(lds, baseT, hbase, off, 0.0, fhi, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, false, true, FMA>(lds, baseT, hbase, off, 0.0, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         fhi = fhi_n;
     }
 }
 
-template <int PPT, int HPT, int MODE, bool VEC2>
+template <int PPT, int HPT, int MODE, bool VEC2, bool FMA>
 __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
     extern __shared__ double2 vw_smem[];
-    char* lds = reinterpret_cast<char*>(vw_smem);
-    double* buf = reinterpret_cast<double*>(vw_smem);
     constexpr int HALO = HPT * kChunk;
     constexpr int T = PPT * kChunk;
+    constexpr int M = HALO + T;
+    // two buffers: level j reads one and writes V_j into the other, so a single barrier per level
+    // is enough (nobody can still be reading the buffer that is being overwritten)
+    double* buf = reinterpret_cast<double*>(vw_smem);
+    double* nxt = buf + M;
     const int tid = threadIdx.x;
+    stagger_start(a.stagger_blocks, a.stagger_unit);
 
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
@@ -308,8 +343,6 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
         int hbase[HPT];
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) av[k][0] = av[k][1] = aw[k][0] = aw[k][1] = 0.0;
-#pragma unroll
         for (int c = 0; c < HPT; ++c) {
             ah[c][0] = ah[c][1] = 0.0;
             const int p = c * kChunk + 2 * tid;
@@ -318,10 +351,11 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
             hwrite[c] = wact[c] && (p >= ps);
             hbase[c] = (p >= ps ? p : ps) * 8;
         }
+        const char* lds = reinterpret_cast<const char*>(buf);
         if (s == 1)
-            fwd_level<PPT, HPT, true>(lds, a, s, tid, av, aw, ah, hbase, wact);
+            fwd_level<PPT, HPT, true, FMA>(lds, a, s, tid, av, aw, ah, hbase, wact);
         else
-            fwd_level<PPT, HPT, false>(lds, a, s, tid, av, aw, ah, hbase, wact);
+            fwd_level<PPT, HPT, false, FMA>(lds, a, s, tid, av, aw, ah, hbase, wact);
 
         // ---- W_j straight to HBM -------------------------------------------------
         double* __restrict__ wrow = a.wout + row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
@@ -348,10 +382,9 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
                 }
             }
         } else {
-            lds_barrier();  // every lane has finished reading V_{j-1}
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
-                *reinterpret_cast<double2*>(buf + HALO + k * kChunk + 2 * tid) = make_double2(av[k][0], av[k][1]);
+                *reinterpret_cast<double2*>(nxt + HALO + k * kChunk + 2 * tid) = make_double2(av[k][0], av[k][1]);
 #pragma unroll
             for (int c = 0; c < HPT; ++c) {
                 if (hwrite[c]) {
@@ -362,10 +395,13 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
                         if (t < 0) v.x = 0.0;
                         if (t + 1 < 0) v.y = 0.0;
                     }
-                    *reinterpret_cast<double2*>(buf + c * kChunk + 2 * tid) = v;
+                    *reinterpret_cast<double2*>(nxt + c * kChunk + 2 * tid) = v;
                 }
             }
             lds_barrier();
+            double* tmp = buf;
+            buf = nxt;
+            nxt = tmp;
         }
     }
 }
@@ -382,7 +418,7 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
 // Tile chunks (k < PPT) are always computed; halo chunks are switched on per
 // wave, lanes right of the needed zone recompute the last needed pair (clamped
 // address, result not written back) -- see fwd_tap.
-template <int PPT, int NP, bool S1>
+template <int PPT, int NP, bool S1, bool FMA>
 __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, const InvArgs& a, int s,
                                           double (&acc)[NP][2], const int (&pb)[NP], const bool (&wact)[NP]) {
     double r1[NP], w1[NP];
@@ -422,8 +458,13 @@ __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, co
         for (int k = 0; k < NP; ++k) {
             if ((k < PPT) || wact[k]) {
                 // sum += lo[l]*a[idx] + hi[l]*d[idx]
-                acc[k][0] = acc[k][0] + (flo * r[k].x + fhi * w[k].x);
-                acc[k][1] = acc[k][1] + (flo * r[k].y + fhi * w[k].y);
+                if (FMA) {
+                    acc[k][0] = __builtin_fma(flo, r[k].x, __builtin_fma(fhi, w[k].x, acc[k][0]));
+                    acc[k][1] = __builtin_fma(flo, r[k].y, __builtin_fma(fhi, w[k].y, acc[k][1]));
+                } else {
+                    acc[k][0] = acc[k][0] + (flo * r[k].x + fhi * w[k].x);
+                    acc[k][1] = acc[k][1] + (flo * r[k].y + fhi * w[k].y);
+                }
             }
         }
         off += sb;
@@ -461,7 +502,7 @@ __device__ __forceinline__ void inv_fetch(const double* __restrict__ src, bool u
     }
 }
 
-template <int PPT, int HPT, int MODE, bool VEC2>
+template <int PPT, int HPT, int MODE, bool VEC2, bool FMA>
 __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
     extern __shared__ double2 vw_smem[];
     constexpr int NP = PPT + HPT;
@@ -472,6 +513,7 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
     const char* ldsW = reinterpret_cast<const char*>(bufW);
     constexpr int T = PPT * kChunk;
     const int tid = threadIdx.x;
+    stagger_start(a.stagger_blocks, a.stagger_unit);
 
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
@@ -537,9 +579,9 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
             pb[k] = ((k < PPT || p < pe) ? p : pe - 2) * 8;
         }
         if (s == 1)
-            inv_level<PPT, NP, true>(ldsR, ldsW, a, s, acc, pb, wact);
+            inv_level<PPT, NP, true, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
         else
-            inv_level<PPT, NP, false>(ldsR, ldsW, a, s, acc, pb, wact);
+            inv_level<PPT, NP, false, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
 
         if (j == a.lev0) {
             double* __restrict__ orow = a.rout + row * a.rout_stride;
