@@ -54,6 +54,44 @@ def test_multilevel_forward_inverse_bit_exact(ctx, wn, n, j, b, mode):
         assert np.abs(gotx - x).max() < tol * max(1.0, np.abs(x).max())
 
 
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("wgs", [1, 6, 24])
+@pytest.mark.parametrize("wn,n,j,b,tile", [("db4", 16384, 6, 3, None), ("db4", 16390, 6, 2, "2,1"), ("haar", 9000, 8, 2, "1,1"),
+                                           ("sym4", 20000, 5, 2, None), ("bior2.2", 12288, 6, 2, "2,1"),
+                                           ("db2", 40000, 7, 1, "4,1"), ("db4", 5121, 5, 3, "1,1")])
+def test_streaming_runs_bit_exact(ctx, monkeypatch, wn, n, j, b, tile, wgs, mode):
+    """The tile-streaming kernels: one workgroup walks several consecutive tiles of a row and carries
+    the level histories in LDS.  VW_STREAM_WGS (wanted workgroups per launch) is lowered so that small
+    batches exercise whole-row runs (1), runs that start mid-row (6) and short runs (24)."""
+    monkeypatch.setenv("VW_STREAM_WGS", str(wgs))
+    if tile:
+        monkeypatch.setenv("VW_FWD_TILE", tile)
+        monkeypatch.setenv("VW_INV_TILE", tile)
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=n + j + wgs)
+    st, want = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    st, got, _ = gpu_forward(ctx, x, wn, j, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "streaming forward %s N=%d J=%d wgs=%d" % (wn, n, j, wgs))
+    wantx = o.reconstruct_batch(want, w, mode)
+    st, gotx, _ = gpu_inverse(ctx, want, wn, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(gotx, wantx, "streaming inverse %s N=%d J=%d wgs=%d" % (wn, n, j, wgs))
+    # denoise rides the same kernels (threshold applied as W_j is staged, heads saved thresholded)
+    st, wantd = o.swt_denoise_batch(x, w, j, -1.0, True, mode)
+    assert st == 0
+    st, gotd, _ = gpu_denoise(ctx, x, wn, j, mode, -1.0, True)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(gotd, wantd, "streaming denoise")
+    # first non-finite index is reported across tile boundaries of a run
+    xb = x.copy()
+    bad_at = (b - 1) * n + (n * 2) // 3
+    xb.reshape(-1)[bad_at] = np.nan
+    st, _, bad = gpu_forward(ctx, xb, wn, j, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == bad_at
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("wn", ["haar", "db4", "sym8", "bior4.4"])
 @pytest.mark.parametrize("n,b", [(1, 2), (5, 3), (8, 1), (63, 4), (64, 4), (1000, 32), (2049, 2)])

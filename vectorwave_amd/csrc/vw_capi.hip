@@ -154,63 +154,76 @@ extern "C" int32_t vw_max_levels(int64_t n, int32_t filter_len) {
 static constexpr int kHaloMaxChunks = 10;  // largest HPT instantiated
 
 struct TileCfg {
-    int ppt, hpt;
+    int ppt, hpt, nt;  // tile = ppt chunks of 2*nt samples, halo = hpt * 512 samples, nt lanes per workgroup
+    int tile() const { return ppt * 2 * nt; }
+    // forward shapes with a one-chunk halo run the tile-streaming kernel (one buffer + level histories);
+    // everything else runs the one-tile-per-workgroup kernels (two buffers)
+    size_t lds_bytes(bool inverse) const {
+        const size_t m = static_cast<size_t>(tile()) + static_cast<size_t>(hpt) * kChunk;
+        if (!inverse && hpt == 1) return (m + kChunk) * 8;
+        return 2 * m * 8;
+    }
 };
 
-// Instantiated (PPT, HPT) pairs.  Keep in sync with the dispatch switch below.
-static const TileCfg kCfgs[] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {8, 2}, {8, 4}, {8, 10}};
+// Instantiated shapes, each list in order of preference within one halo size (measured on MI355X, DB4
+// J=6, 65536 x 16384).  Keep in sync with the dispatch below.
+//   forward: 1024-sample tiles streamed along the row beat larger ones (more resident workgroups)
+//   inverse, reference arithmetic: 2048-sample tiles (128 VGPRs, four workgroups per CU)
+//   inverse, fused multiply-add: the loop is LDS-bound and 4096-sample tiles amortise the halo best
+static const TileCfg kFwdCfgs[] = {{2, 1, 256}, {4, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
+static const TileCfg kInvCfgs[] = {{4, 1, 256}, {2, 1, 256}, {8, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
+static const TileCfg kInvCfgsFma[] = {{8, 1, 256}, {4, 1, 256}, {2, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
+
+struct CfgList {
+    const TileCfg* v;
+    int n;
+    bool inverse;
+};
+static CfgList fwd_cfgs() { return CfgList{kFwdCfgs, static_cast<int>(sizeof(kFwdCfgs) / sizeof(TileCfg)), false}; }
+static CfgList inv_cfgs(bool fma) {
+    const int n = static_cast<int>(sizeof(kInvCfgs) / sizeof(TileCfg));
+    return CfgList{fma ? kInvCfgsFma : kInvCfgs, n, true};
+}
 
 // Tuning hook: VW_FWD_TILE / VW_INV_TILE = "<ppt>,<hpt>" force an instantiated tile shape
 // (ignored when the halo does not fit it).
-static bool env_cfg(bool inverse, int hpt_need, TileCfg* out) {
-    const char* e = getenv(inverse ? "VW_INV_TILE" : "VW_FWD_TILE");
+static bool env_cfg(const CfgList& cl, int hpt_need, TileCfg* out) {
+    const char* e = getenv(cl.inverse ? "VW_INV_TILE" : "VW_FWD_TILE");
     if (e == nullptr) return false;
     int p = 0, h = 0;
     if (sscanf(e, "%d,%d", &p, &h) != 2) return false;
-    for (const TileCfg& c : kCfgs)
-        if (c.ppt == p && c.hpt == h && h >= hpt_need) {
-            *out = c;
+    for (int i = 0; i < cl.n; ++i)
+        if (cl.v[i].ppt == p && cl.v[i].hpt == h && h >= hpt_need) {
+            *out = cl.v[i];
             return true;
         }
     return false;
 }
 
-static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, bool inverse, TileCfg* out) {
+static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, const CfgList& cl, TileCfg* out) {
     // two samples of slack: pair alignment may start a pair one sample outside the exact need
     int hpt_need = static_cast<int>((halo + 2 + kChunk - 1) / kChunk);
     if (hpt_need < 1) hpt_need = 1;
-    int64_t row_chunks = (n + kChunk - 1) / kChunk;  // chunks that cover one row
-    if (row_chunks < 1) row_chunks = 1;
-    if (env_cfg(inverse, hpt_need, out)) return true;
-    const int ncfg = static_cast<int>(sizeof(kCfgs) / sizeof(kCfgs[0]));
+    if (env_cfg(cl, hpt_need, out)) return true;
     // smallest instantiated halo that covers the need and fits LDS
     int hpt = 0;
-    for (int i = 0; i < ncfg; ++i) {
-        const TileCfg& c = kCfgs[i];
-        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * 2;  // two buffers in both directions
-        if (c.hpt < hpt_need || lds > static_cast<size_t>(lds_limit)) continue;
+    for (int i = 0; i < cl.n; ++i) {
+        const TileCfg& c = cl.v[i];
+        if (c.hpt < hpt_need || c.lds_bytes(cl.inverse) > static_cast<size_t>(lds_limit)) continue;
         if (hpt == 0 || c.hpt < hpt) hpt = c.hpt;
     }
     if (hpt == 0) return false;
-    // with that halo: the largest tile that does not exceed the row, else the smallest tile
-    int best = -1;
-    for (int i = 0; i < ncfg; ++i) {
-        const TileCfg& c = kCfgs[i];
-        const size_t lds = static_cast<size_t>(c.ppt + c.hpt) * kChunk * 8 * 2;  // two buffers in both directions
-        if (c.hpt != hpt || lds > static_cast<size_t>(lds_limit)) continue;
-        if (best < 0) {
-            best = i;
-            continue;
-        }
-        const TileCfg& b = kCfgs[best];
-        // measured on MI355X (DB4 J=6, 65536 x 16384): 2048-sample tiles run a few percent faster
-        // than 4096-sample ones in both directions (more resident workgroups per CU outweigh the
-        // extra halo), so tiles above 4 chunks are used only when the halo forces them
-        const int cap = 4;
-        const bool c_in = c.ppt <= row_chunks && c.ppt <= cap, b_in = b.ppt <= row_chunks && b.ppt <= cap;
-        if ((c_in && (!b_in || c.ppt > b.ppt)) || (!c_in && !b_in && c.ppt < b.ppt)) best = i;
+    // with that halo: the first shape in preference order whose tile does not exceed the row
+    // (rounded up to a chunk), else the smallest tile
+    const int64_t row_len = (n + kChunk - 1) / kChunk * kChunk;
+    int best = -1, smallest = -1;
+    for (int i = 0; i < cl.n; ++i) {
+        const TileCfg& c = cl.v[i];
+        if (c.hpt != hpt || c.lds_bytes(cl.inverse) > static_cast<size_t>(lds_limit)) continue;
+        if (smallest < 0 || c.tile() < cl.v[smallest].tile()) smallest = i;
+        if (best < 0 && c.tile() <= row_len) best = i;
     }
-    *out = kCfgs[best];
+    *out = cl.v[best >= 0 ? best : smallest];
     return true;
 }
 
@@ -263,6 +276,17 @@ static hipError_t launch_tile(K kernel, const A& args, int64_t nblocks, size_t l
     return hipGetLastError();
 }
 
+template <typename K, typename A>
+static hipError_t launch_tile_nt(K kernel, const A& args, int nt, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nblocks)), dim3(nt), lds, stream, args);
+    return hipGetLastError();
+}
+
 template <int P, int H, int MODE>
 static hipError_t launch_fwd_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
     if (vec2) return fma ? launch_tile(k_fwd_fused<P, H, MODE, true, true>, a, nblocks, lds, stream)
@@ -277,19 +301,35 @@ static hipError_t launch_inv_pm(const InvArgs& a, bool vec2, bool fma, int64_t n
     return fma ? launch_tile(k_inv_fused<P, H, MODE, false, true>, a, nblocks, lds, stream)
                : launch_tile(k_inv_fused<P, H, MODE, false, false>, a, nblocks, lds, stream);
 }
-
+template <int NT, int P, int MODE, int LT>
+static hipError_t launch_fwd_stream_lt(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile_nt(k_fwd_stream<NT, P, MODE, true, true, LT>, a, NT, nblocks, lds, stream)
+                         : launch_tile_nt(k_fwd_stream<NT, P, MODE, true, false, LT>, a, NT, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_fwd_stream<NT, P, MODE, false, true, 0>, a, NT, nblocks, lds, stream)
+               : launch_tile_nt(k_fwd_stream<NT, P, MODE, false, false, 0>, a, NT, nblocks, lds, stream);
+}
+// filters of exactly 8 + 8 taps (db4, sym4, ...) on 16-byte-aligned rows take the fully unrolled tap loop
+template <int NT, int P, int MODE>
+static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (a.lh == 8 && a.lg == 8 && getenv("VW_NO_UNROLL") == nullptr)
+        return launch_fwd_stream_lt<NT, P, MODE, 8>(a, vec2, fma, nblocks, lds, stream);
+    return launch_fwd_stream_lt<NT, P, MODE, 0>(a, vec2, fma, nblocks, lds, stream);
+}
 #define VW_FWD_CASE(P, H)                                                                                    \
-    if (cfg.ppt == P && cfg.hpt == H)                                                                        \
+    if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
         return mode == kPeriodic ? launch_fwd_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
                                  : launch_fwd_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+#define VW_FWD_STREAM_CASE(NT, P)                                                                            \
+    if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == NT)                                                        \
+        return mode == kPeriodic ? launch_fwd_stream_pm<NT, P, kPeriodic>(a, vec2, fma, nblocks, lds, stream) \
+                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
 
 static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
                              hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8 * 2;
-    VW_FWD_CASE(1, 1)
-    VW_FWD_CASE(2, 1)
-    VW_FWD_CASE(4, 1)
-    VW_FWD_CASE(8, 1)
+    const size_t lds = cfg.lds_bytes(false);
+    VW_FWD_STREAM_CASE(256, 1)
+    VW_FWD_STREAM_CASE(256, 2)
+    VW_FWD_STREAM_CASE(256, 4)
     VW_FWD_CASE(4, 2)
     VW_FWD_CASE(8, 2)
     VW_FWD_CASE(8, 4)
@@ -298,13 +338,12 @@ static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2,
 }
 
 #define VW_INV_CASE(P, H)                                                                                    \
-    if (cfg.ppt == P && cfg.hpt == H)                                                                        \
+    if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
         return mode == kPeriodic ? launch_inv_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
                                  : launch_inv_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-
 static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
                              hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(cfg.ppt + cfg.hpt) * kChunk * 8 * 2;
+    const size_t lds = cfg.lds_bytes(true);
     VW_INV_CASE(1, 1)
     VW_INV_CASE(2, 1)
     VW_INV_CASE(4, 1)
@@ -314,6 +353,39 @@ static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2,
     VW_INV_CASE(8, 4)
     VW_INV_CASE(8, 10)
     return hipErrorInvalidValue;
+}
+
+// Streaming forward: split each row into runs of consecutive tiles, one workgroup per run.  Long runs
+// amortise the one halo a run pays for; short runs keep enough workgroups in flight when the batch
+// is small.  VW_FWD_CHUNKS caps the run length (1 = one tile per workgroup, as the halo kernels do).
+static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
+    int off = 0;
+    for (int j = a->lev0; j <= a->lev1; ++j) {
+        const int64_t hl = (static_cast<int64_t>(lmax - 1) * (static_cast<int64_t>(1) << (j - 1)) + 1) & ~static_cast<int64_t>(1);
+        if (hl > kChunk - 2 || off + hl > kChunk) return;  // history does not fit: keep one tile per workgroup
+        a->hoff[j] = off;
+        a->hlen[j] = static_cast<int32_t>(hl);
+        off += static_cast<int>(hl);
+    }
+    int64_t cap = 64;
+    if (const char* e = getenv("VW_FWD_CHUNKS")) {
+        const long v = atol(e);
+        if (v >= 1) cap = v;
+    }
+    const int64_t tiles = a->tiles_per_row;
+    int64_t want_wgs = 16384;  // several rounds of resident workgroups on 256 CUs
+    if (const char* e = getenv("VW_STREAM_WGS")) {  // test / tuning hook
+        const long v = atol(e);
+        if (v >= 1) want_wgs = v;
+    }
+    int64_t nseg = rows > 0 ? (want_wgs + rows - 1) / rows : 1;
+    if (nseg < 1) nseg = 1;
+    if (nseg > tiles) nseg = tiles;
+    int64_t nch = (tiles + nseg - 1) / nseg;
+    if (nch > cap) nch = cap;
+    if (nch < 1) nch = 1;
+    a->nchunks = static_cast<int32_t>(nch);
+    a->ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
 }
 
 // VW_STAGGER="<blocks>,<unit>" overrides the start-up stagger (0,0 switches it off).
@@ -404,18 +476,18 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             st.lev0 = j;
             st.lev1 = j;
             st.fused = false;
-            st.cfg = TileCfg{0, 0};
+            st.cfg = TileCfg{0, 0, kThreads};
             if (!generic_all) {
                 int hi = j;
                 TileCfg cfg;
-                if (pick_cfg(n, fwd_halo(j, j, lh, lg, nullptr), ctx->lds_limit, false, &cfg)) {
+                if (pick_cfg(n, fwd_halo(j, j, lh, lg, nullptr), ctx->lds_limit, fwd_cfgs(), &cfg)) {
                     st.fused = true;
                     st.cfg = cfg;
                     while (hi + 1 <= levels) {
                         TileCfg c2;
                         const int64_t hneed = fwd_halo(j, hi + 1, lh, lg, nullptr);
                         if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
-                        if (!pick_cfg(n, hneed, ctx->lds_limit, false, &c2)) break;
+                        if (!pick_cfg(n, hneed, ctx->lds_limit, fwd_cfgs(), &c2)) break;
                         st.cfg = c2;
                         ++hi;
                     }
@@ -456,12 +528,15 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             a.n = n;
             a.n_store = n;
             a.nrows = b;
-            const int T = st.cfg.ppt * kChunk;
+            const int T = st.cfg.tile();
             a.ntiles = static_cast<int32_t>((n + T - 1) / T);
+            a.tiles_per_row = a.ntiles;
+            a.nchunks = 1;
             a.lev0 = st.lev0;
             a.lev1 = st.lev1;
             a.lh = lh;
             a.lg = lg;
+            if (st.cfg.hpt == 1) plan_stream(&a, b, lh > lg ? lh : lg);
             if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
@@ -631,10 +706,10 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             st.lev0 = j;
             st.lev1 = j;
             st.fused = false;
-            st.cfg = TileCfg{0, 0};
+            st.cfg = TileCfg{0, 0, kThreads};
             if (!generic_all) {
                 TileCfg cfg;
-                if (pick_cfg(n, inv_halo(j, j, lhr), ctx->lds_limit, true, &cfg)) {
+                if (pick_cfg(n, inv_halo(j, j, lhr), ctx->lds_limit, inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg)) {
                     st.fused = true;
                     st.cfg = cfg;
                     int lo = j;
@@ -642,7 +717,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                         TileCfg c2;
                         const int64_t hneed = inv_halo(lo - 1, j, lhr);
                         if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
-                        if (!pick_cfg(n, hneed, ctx->lds_limit, true, &c2)) break;
+                        if (!pick_cfg(n, hneed, ctx->lds_limit, inv_cfgs((flags & VW_FLAG_FMA) != 0), &c2)) break;
                         st.cfg = c2;
                         --lo;
                     }
@@ -682,8 +757,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.n = n;
             a.n_store = n;
             a.nrows = b;
-            const int T = st.cfg.ppt * kChunk;
-            const int M = (st.cfg.ppt + st.cfg.hpt) * kChunk;
+            const int T = st.cfg.tile();
+            const int M = T + st.cfg.hpt * kChunk;
             a.ntiles = static_cast<int32_t>((n + T - 1) / T);
             a.lev0 = st.lev0;
             a.lev1 = st.lev1;

@@ -53,6 +53,10 @@ struct FwdArgs {
     int32_t lev0, lev1;    // levels computed by this launch (inclusive)
     int32_t lh, lg;        // tap counts of lo / hi
     int32_t pstart[kMaxLevels + 1];  // first buffer position at which V_j is computed (even)
+    // streaming kernel only: a workgroup walks `nchunks` consecutive tiles of its row and carries the
+    // last hlen[j] samples of V_{j-1} (the left context level j needs) from tile to tile in LDS
+    int32_t tiles_per_row, nchunks;
+    int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     unsigned long long* first_bad;   // nullptr = no finite check
     Taps taps;
 };
@@ -173,7 +177,7 @@ __device__ __forceinline__ double mac(double acc, double x, double f) {
     return FMA ? __builtin_fma(x, f, acc) : acc + x * f;
 }
 
-template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI, bool FMA, bool FIRST = false>
+template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI, bool FMA, bool FIRST = false, int CH = kChunk>
 __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&hbase)[HPT], int off, double flo,
                                         double fhi, double (&av)[PPT][2], double (&aw)[PPT][2],
                                         double (&ah)[HPT][2], double (&xp)[PPT], double (&xph)[HPT],
@@ -182,11 +186,11 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         if (S1) {
-            xt[k].x = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) - off);
+            xt[k].x = *reinterpret_cast<const double*>(lds + baseT + k * (CH * 8) - off);
             xt[k].y = xp[k];
             xp[k] = xt[k].x;
         } else {
-            xt[k] = *reinterpret_cast<const double2*>(lds + baseT + k * (kChunk * 8) - off);
+            xt[k] = *reinterpret_cast<const double2*>(lds + baseT + k * (CH * 8) - off);
         }
     }
 #pragma unroll
@@ -223,7 +227,10 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
     }
 }
 
-template <int PPT, int HPT, bool S1, bool FMA>
+// LT > 0: both filters have exactly LT taps; the tap loop is unrolled completely and the 2*LT tap
+// values are fetched in one go, so no scalar load (which shares its completion counter with the LDS
+// reads) sits inside the loop.  LT == 0: any lengths, one tap per iteration, taps fetched one ahead.
+template <int PPT, int HPT, bool S1, bool FMA, int CH = kChunk, int LT = 0>
 __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int s, int tid,
                                           double (&av)[PPT][2], double (&aw)[PPT][2],
                                           double (&ah)[HPT][2], const int (&hbase)[HPT], const bool (&wact)[HPT]) {
@@ -233,20 +240,34 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
     if (S1) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            xp[k] = *reinterpret_cast<const double*>(lds + baseT + k * (kChunk * 8) + 8);
+            xp[k] = *reinterpret_cast<const double*>(lds + baseT + k * (CH * 8) + 8);
 #pragma unroll
         for (int c = 0; c < HPT; ++c)
             xph[c] = wact[c] ? *reinterpret_cast<const double*>(lds + hbase[c] + 8) : 0.0;
     }
+    const int sb = s * 8;
+    if (LT > 0) {
+        double tl[LT > 0 ? LT : 1], th[LT > 0 ? LT : 1];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) {
+            tl[i] = a.taps.lo[i];
+            th[i] = a.taps.hi[i];
+        }
+        fwd_tap<PPT, HPT, S1, true, true, FMA, true, CH>(lds, baseT, hbase, 0, tl[0], th[0], av, aw, ah, xp, xph, wact);
+#pragma unroll
+        for (int i = 1; i < LT; ++i)
+            fwd_tap<PPT, HPT, S1, true, true, FMA, false, CH>(lds, baseT, hbase, i * sb, tl[i], th[i], av, aw, ah, xp,
+                                                              xph, wact);
+        return;
+    }
     const int lh = a.lh, lg = a.lg;
     const int lmin = lh < lg ? lh : lg;
-    const int sb = s * 8;
     int off = 0;
     int l = 0;
     double flo = a.taps.lo[0], fhi = a.taps.hi[0];
     if (lmin > 0) {  // tap 0 defines the tile accumulators
         const double flo_n = a.taps.lo[1], fhi_n = a.taps.hi[1];
-        fwd_tap<PPT, HPT, S1, true, true, FMA, true>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, true, FMA, true, CH>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
         fhi = fhi_n;
@@ -254,20 +275,20 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
     }
     for (; l < lmin; ++l) {
         const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, true, true, FMA>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, true, FMA, false, CH>(lds, baseT, hbase, off, flo, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
         fhi = fhi_n;
     }
     for (; l < lh; ++l) {  // low-pass longer than high-pass
         const double flo_n = a.taps.lo[l + 1];
-        fwd_tap<PPT, HPT, S1, true, false, FMA>(lds, baseT, hbase, off, flo, 0.0, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, false, FMA, false, CH>(lds, baseT, hbase, off, flo, 0.0, av, aw, ah, xp, xph, wact);
         off += sb;
         flo = flo_n;
     }
     for (; l < lg; ++l) {  // high-pass longer than low-pass
         const double fhi_n = a.taps.hi[l + 1];
-        fwd_tap<PPT, HPT, S1, false, true, FMA>(lds, baseT, hbase, off, 0.0, fhi, av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, false, true, FMA, false, CH>(lds, baseT, hbase, off, 0.0, fhi, av, aw, ah, xp, xph, wact);
         off += sb;
         fhi = fhi_n;
     }
@@ -407,6 +428,200 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// streaming forward: one workgroup walks a run of consecutive tiles of one row
+// ---------------------------------------------------------------------------
+//
+// Same tile engine as k_fwd_fused with a 512-sample halo, but only the first tile of the run pays
+// for the halo (loaded from HBM and recomputed level by level).  For every later tile the left
+// context of level j is the tail of V_{j-1} of the previous tile, kept in a small LDS history array,
+// so no halo sample is loaded or recomputed again; the next tile's input is fetched from HBM into
+// registers while the current tile is computed.  The lane that owns a tail pair both consumes the
+// old history entry and replaces it, so the history needs no second copy and no extra barrier.
+//
+// NT lanes per workgroup (256 or 512); a tile chunk is 2*NT samples, the halo is owned by the first
+// 256 lanes.  Buffer position p <-> sample t0 - 512 + p.
+template <int NT, int PPT, int MODE, bool VEC2, bool FMA, int LT = 0>
+__global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int HPT = 1;
+    constexpr int HALO = kChunk;
+    constexpr int CH = 2 * NT;
+    constexpr int T = PPT * CH;
+    constexpr int M = HALO + T;
+    double* buf = reinterpret_cast<double*>(vw_smem);
+    double* hst = buf + M;  // kChunk doubles
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool hwave = wave < kThreads / 64;  // waves whose lanes own a halo pair
+    stagger_start(a.stagger_blocks, a.stagger_unit);
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int seg = static_cast<int>(id - row * a.ntiles);
+    const int tile0 = seg * a.nchunks;
+    int ntl = a.tiles_per_row - tile0;
+    if (ntl > a.nchunks) ntl = a.nchunks;
+    const int64_t n = a.n;
+    const int64_t ns = a.n_store;
+    const double* __restrict__ inrow = a.in + row * a.in_stride;
+    const bool carry = ntl > 1;
+
+    double2 pre[PPT];
+    for (int ch = 0; ch < ntl; ++ch) {
+        const int64_t t0 = static_cast<int64_t>(tile0 + ch) * T;
+        const bool warm = (ch == 0);
+        // ---- stage V_{lev0-1} -------------------------------------------------------
+        if (warm) {
+            if (hwave) {
+                const int64_t t = t0 - HALO + 2 * tid;
+                double2 x = make_double2(0.0, 0.0);
+                if (t >= 0) {
+                    if (VEC2) {
+                        if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
+                    } else {
+                        if (t < n) x.x = inrow[t];
+                        if (t + 1 < n) x.y = inrow[t + 1];
+                    }
+                } else if (MODE == kPeriodic) {
+                    if (VEC2) {
+                        x = *reinterpret_cast<const double2*>(inrow + mod_wrap(t, n));
+                    } else {
+                        x.x = inrow[mod_wrap(t, n)];
+                        x.y = inrow[mod_wrap(t + 1, n)];
+                    }
+                }
+                *reinterpret_cast<double2*>(buf + 2 * tid) = x;
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * CH + 2 * tid;
+                double2 x = make_double2(0.0, 0.0);
+                if (VEC2) {
+                    if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
+                } else {
+                    if (t < n) x.x = inrow[t];
+                    if (t + 1 < n) x.y = inrow[t + 1];
+                }
+                pre[k] = x;
+            }
+        }
+        if (a.first_bad != nullptr) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * CH + 2 * tid;
+                if (t < n && !finite_f64(pre[k].x))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
+                if (t + 1 < n && !finite_f64(pre[k].y))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) *reinterpret_cast<double2*>(buf + HALO + k * CH + 2 * tid) = pre[k];
+        if (carry) {
+            const int hl = a.hlen[a.lev0];
+            const int i = 2 * tid - (CH - hl);
+            if (i >= 0) {
+                double2* h = reinterpret_cast<double2*>(hst + a.hoff[a.lev0] + i);
+                const double2 old = *h;
+                *h = pre[PPT - 1];
+                if (!warm) *reinterpret_cast<double2*>(buf + HALO - hl + i) = old;
+            }
+        }
+        lds_barrier();
+
+        // ---- next tile's input: in flight while this tile is computed ---------------
+        if (ch + 1 < ntl) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + T + k * CH + 2 * tid;
+                double2 x = make_double2(0.0, 0.0);
+                if (VEC2) {
+                    if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
+                } else {
+                    if (t < n) x.x = inrow[t];
+                    if (t + 1 < n) x.y = inrow[t + 1];
+                }
+                pre[k] = x;
+            }
+        }
+
+        for (int j = a.lev0; j <= a.lev1; ++j) {
+            const int s = 1 << (j - 1);
+            const int ps = a.pstart[j];
+            double av[PPT][2], aw[PPT][2], ah[HPT][2];
+            bool wact[HPT], hwrite[HPT];
+            int hbase[HPT];
+            {
+                ah[0][0] = ah[0][1] = 0.0;
+                const int p = 2 * tid;
+                // halo samples are recomputed for the first tile only, and never for the last level
+                wact[0] = warm && hwave && (j < a.lev1) && (128 * wave + 128 > ps);
+                hwrite[0] = wact[0] && (p >= ps);
+                hbase[0] = (p >= ps ? p : ps) * 8;
+            }
+            const char* lds = reinterpret_cast<const char*>(buf);
+            if (s == 1)
+                fwd_level<PPT, HPT, true, FMA, CH, LT>(lds, a, s, tid, av, aw, ah, hbase, wact);
+            else
+                fwd_level<PPT, HPT, false, FMA, CH, LT>(lds, a, s, tid, av, aw, ah, hbase, wact);
+
+            double* __restrict__ wrow =
+                a.wout + row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * CH + 2 * tid;
+                if (VEC2) {
+                    if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                } else {
+                    if (t < ns) wrow[t] = aw[k][0];
+                    if (t + 1 < ns) wrow[t + 1] = aw[k][1];
+                }
+            }
+            if (j == a.lev1) {
+                double* __restrict__ vrow = a.vout + row * a.v_stride;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int64_t t = t0 + k * CH + 2 * tid;
+                    if (VEC2) {
+                        if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                    } else {
+                        if (t < ns) vrow[t] = av[k][0];
+                        if (t + 1 < ns) vrow[t + 1] = av[k][1];
+                    }
+                }
+                if (ch + 1 < ntl) lds_barrier();  // last reads of this tile done before it is restaged
+            } else {
+                lds_barrier();  // every lane has finished reading V_{j-1}
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    *reinterpret_cast<double2*>(buf + HALO + k * CH + 2 * tid) = make_double2(av[k][0], av[k][1]);
+                if (hwrite[0]) {
+                    double2 v = make_double2(ah[0][0], ah[0][1]);
+                    if (MODE == kZeroPad) {
+                        // samples left of the signal are zero at every level
+                        const int64_t t = t0 - HALO + 2 * tid;
+                        if (t < 0) v.x = 0.0;
+                        if (t + 1 < 0) v.y = 0.0;
+                    }
+                    *reinterpret_cast<double2*>(buf + 2 * tid) = v;
+                }
+                if (carry) {
+                    const int hl = a.hlen[j + 1];
+                    const int i = 2 * tid - (CH - hl);
+                    if (i >= 0) {
+                        double2* h = reinterpret_cast<double2*>(hst + a.hoff[j + 1] + i);
+                        const double2 old = *h;
+                        *h = make_double2(av[PPT - 1][0], av[PPT - 1][1]);
+                        if (!warm) *reinterpret_cast<double2*>(buf + HALO - hl + i) = old;
+                    }
+                }
+                lds_barrier();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fused inverse: levels lev1 down to lev0 of one (row, tile) per workgroup
 // ---------------------------------------------------------------------------
 //
@@ -418,55 +633,68 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
 // Tile chunks (k < PPT) are always computed; halo chunks are switched on per
 // wave, lanes right of the needed zone recompute the last needed pair (clamped
 // address, result not written back) -- see fwd_tap.
+template <int PPT, int NP, bool S1>
+__device__ __forceinline__ void inv_read(const char* ldsR, const char* ldsW, const int (&pb)[NP], int off,
+                                         const bool (&wact)[NP], const double2 (&rc)[NP], const double2 (&wc)[NP],
+                                         double2 (&r)[NP], double2 (&w)[NP]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if ((k < PPT) || wact[k]) {
+            if (S1) {
+                // pair (p, p+1) reads positions p+l and p+1+l: slide by one per tap
+                r[k].x = rc[k].y;
+                w[k].x = wc[k].y;
+                r[k].y = *reinterpret_cast<const double*>(ldsR + pb[k] + off + 8);
+                w[k].y = *reinterpret_cast<const double*>(ldsW + pb[k] + off + 8);
+            } else {
+                r[k] = *reinterpret_cast<const double2*>(ldsR + pb[k] + off);
+                w[k] = *reinterpret_cast<const double2*>(ldsW + pb[k] + off);
+            }
+        }
+    }
+}
+
+template <int PPT, int NP, bool FMA>
+__device__ __forceinline__ void inv_mac(double flo, double fhi, const double2 (&rc)[NP], const double2 (&wc)[NP],
+                                        const bool (&wact)[NP], double (&acc)[NP][2]) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if ((k < PPT) || wact[k]) {
+            // sum += lo[l]*a[idx] + hi[l]*d[idx]
+            if (FMA) {
+                acc[k][0] = __builtin_fma(flo, rc[k].x, __builtin_fma(fhi, wc[k].x, acc[k][0]));
+                acc[k][1] = __builtin_fma(flo, rc[k].y, __builtin_fma(fhi, wc[k].y, acc[k][1]));
+            } else {
+                acc[k][0] = acc[k][0] + (flo * rc[k].x + fhi * wc[k].x);
+                acc[k][1] = acc[k][1] + (flo * rc[k].y + fhi * wc[k].y);
+            }
+        }
+    }
+}
+
+// One level of one tile: taps in ascending order, the next tap's filter values fetched one ahead.
 template <int PPT, int NP, bool S1, bool FMA>
 __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, const InvArgs& a, int s,
                                           double (&acc)[NP][2], const int (&pb)[NP], const bool (&wact)[NP]) {
-    double r1[NP], w1[NP];
-    if (S1) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const bool on = (k < PPT) || wact[k];
-            r1[k] = on ? *reinterpret_cast<const double*>(ldsR + pb[k]) : 0.0;
-            w1[k] = on ? *reinterpret_cast<const double*>(ldsW + pb[k]) : 0.0;
-        }
-    }
     const int lh = a.lh;
     const int sb = s * 8;
+    double2 r[NP], w[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        r[k] = make_double2(0.0, 0.0);
+        w[k] = make_double2(0.0, 0.0);
+        if (S1 && ((k < PPT) || wact[k])) {  // seed of the sliding window: position p
+            r[k].y = *reinterpret_cast<const double*>(ldsR + pb[k]);
+            w[k].y = *reinterpret_cast<const double*>(ldsW + pb[k]);
+        }
+    }
+    // any length: one tap per trip, the next tap's filter values fetched one ahead
     int off = 0;
     double flo = a.taps.lo[0], fhi = a.taps.hi[0];
     for (int l = 0; l < lh; ++l) {
         const double flo_n = a.taps.lo[l + 1], fhi_n = a.taps.hi[l + 1];
-        double2 r[NP], w[NP];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if ((k < PPT) || wact[k]) {
-                if (S1) {
-                    // pair (p, p+1) reads positions p+l and p+1+l: slide by one per tap
-                    r[k].x = r1[k];
-                    w[k].x = w1[k];
-                    r[k].y = *reinterpret_cast<const double*>(ldsR + pb[k] + off + 8);
-                    w[k].y = *reinterpret_cast<const double*>(ldsW + pb[k] + off + 8);
-                    r1[k] = r[k].y;
-                    w1[k] = w[k].y;
-                } else {
-                    r[k] = *reinterpret_cast<const double2*>(ldsR + pb[k] + off);
-                    w[k] = *reinterpret_cast<const double2*>(ldsW + pb[k] + off);
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if ((k < PPT) || wact[k]) {
-                // sum += lo[l]*a[idx] + hi[l]*d[idx]
-                if (FMA) {
-                    acc[k][0] = __builtin_fma(flo, r[k].x, __builtin_fma(fhi, w[k].x, acc[k][0]));
-                    acc[k][1] = __builtin_fma(flo, r[k].y, __builtin_fma(fhi, w[k].y, acc[k][1]));
-                } else {
-                    acc[k][0] = acc[k][0] + (flo * r[k].x + fhi * w[k].x);
-                    acc[k][1] = acc[k][1] + (flo * r[k].y + fhi * w[k].y);
-                }
-            }
-        }
+        inv_read<PPT, NP, S1>(ldsR, ldsW, pb, off, wact, r, w, r, w);
+        inv_mac<PPT, NP, FMA>(flo, fhi, r, w, wact, acc);
         off += sb;
         flo = flo_n;
         fhi = fhi_n;
