@@ -93,6 +93,29 @@ def test_streaming_runs_bit_exact(ctx, monkeypatch, wn, n, j, b, tile, wgs, mode
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("sym8", 4096, 5, 2), ("haar", 1000, 4, 4), ("bior4.4", 2000, 4, 2),
+                                      ("db10", 9999, 8, 2), ("coif17", 4000, 5, 1)])
+def test_fma_mode_within_north_star_tolerance(ctx, wn, n, j, b, mode):
+    """VW_FLAG_FMA trades bit parity for fused multiply-adds.  Tolerance (the benchmark's stated one):
+    |gpu - ref| <= 1e-12 * max(|ref|, max|x|) per coefficient and per reconstructed sample."""
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=3 * n + j)
+    st, want = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    scale = np.abs(x).max()
+    st, got, _ = gpu_forward(ctx, x, wn, j, mode, N.VW_FLAG_FMA)
+    assert st == 0, ctx.last_error()
+    assert (np.abs(got - want) <= 1e-12 * np.maximum(np.abs(want), scale)).all()
+    wantx = o.reconstruct_batch(want, w, mode)
+    st, gotx, _ = gpu_inverse(ctx, want, wn, mode, N.VW_FLAG_FMA)
+    assert st == 0, ctx.last_error()
+    assert (np.abs(gotx - wantx) <= 1e-12 * np.maximum(np.abs(wantx), scale)).all()
+    if mode == S:
+        # SYMMETRIC runs the generic kernels, which have no fused mode: still bit-exact
+        assert_bits_equal(got, want, "symmetric forward ignores the flag")
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("wn", ["haar", "db4", "sym8", "bior4.4"])
 @pytest.mark.parametrize("n,b", [(1, 2), (5, 3), (8, 1), (63, 4), (64, 4), (1000, 32), (2049, 2)])
 def test_single_level_bit_exact(ctx, wn, n, b, mode):

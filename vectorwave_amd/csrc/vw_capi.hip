@@ -388,19 +388,6 @@ static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
     a->ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
 }
 
-// VW_STAGGER="<blocks>,<unit>" overrides the start-up stagger (0,0 switches it off).
-static void stagger_params(int32_t* blocks, int32_t* unit) {
-    *blocks = 0;
-    *unit = 0;
-    if (const char* e = getenv("VW_STAGGER")) {
-        int b = 0, u = 0;
-        if (sscanf(e, "%d,%d", &b, &u) == 2) {
-            *blocks = b;
-            *unit = u;
-        }
-    }
-}
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------------------
@@ -541,7 +528,6 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
             }
-            stagger_params(&a.stagger_blocks, &a.stagger_unit);
             int64_t hn[kMaxLevels + 2] = {0};
             fwd_halo(st.lev0, st.lev1, lh, lg, hn);
             const int64_t halo = static_cast<int64_t>(st.cfg.hpt) * kChunk;
@@ -783,7 +769,6 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                 if (strstr(dbg, "nohalo"))
                     for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
             }
-            stagger_params(&a.stagger_blocks, &a.stagger_unit);
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");

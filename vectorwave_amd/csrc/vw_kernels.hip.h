@@ -47,7 +47,6 @@ struct FwdArgs {
     int64_t v_stride;
     int64_t n;
     int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
-    int32_t stagger_blocks, stagger_unit;  // see stagger_start
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels computed by this launch (inclusive)
@@ -71,7 +70,6 @@ struct InvArgs {
     int64_t rout_stride;
     int64_t n;
     int64_t n_store;       // == n; 0 in the store-ablation build of the tuning harness
-    int32_t stagger_blocks, stagger_unit;  // see stagger_start
     int64_t nrows;
     int32_t ntiles;
     int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
@@ -107,17 +105,6 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblk) {
 // completed" + s_barrier is all the tile hand-off between waves needs.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// All workgroups do identical work, so the first resident wave of them would otherwise stay phase
-// locked (everyone loads, then everyone computes, then everyone stores) and HBM and the VALUs would
-// take turns idling.  The first `count` workgroups therefore start after a pseudo-random fraction of
-// one tile time; later workgroups inherit the spread because they start when an earlier one ends.
-__device__ __forceinline__ void stagger_start(int count, int unit_sleeps) {
-    if (static_cast<int>(blockIdx.x) < count) {
-        const unsigned k = (static_cast<unsigned>(blockIdx.x) * 2654435761u) >> 29;  // 0..7
-        for (unsigned i = 0; i < k * static_cast<unsigned>(unit_sleeps); ++i) __builtin_amdgcn_s_sleep(64);
-    }
 }
 
 __device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n) {
@@ -305,7 +292,6 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
     double* buf = reinterpret_cast<double*>(vw_smem);
     double* nxt = buf + M;
     const int tid = threadIdx.x;
-    stagger_start(a.stagger_blocks, a.stagger_unit);
 
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
@@ -453,7 +439,6 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool hwave = wave < kThreads / 64;  // waves whose lanes own a halo pair
-    stagger_start(a.stagger_blocks, a.stagger_unit);
 
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
@@ -741,7 +726,6 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
     const char* ldsW = reinterpret_cast<const char*>(bufW);
     constexpr int T = PPT * kChunk;
     const int tid = threadIdx.x;
-    stagger_start(a.stagger_blocks, a.stagger_unit);
 
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
