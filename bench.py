@@ -66,7 +66,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the MODWT engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (RANK/WORLD_SIZE set) the process group is always created, also for one rank, so
+    # the single-GPU box exercises the same barrier / MAX-over-ranks code as the 8-GPU node
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     w = get_wavelet(args.wavelet)
@@ -121,7 +124,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -140,7 +143,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t_start
     barrier()
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -252,7 +255,7 @@ def main():
     }
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -57,3 +57,27 @@ def test_no_gpu_fails_loudly():
     assert lib.vw_init(0, C.byref(h)) == N.VW_E_NO_DEVICE
     with pytest.raises(N.NativeLibraryError):
         N.Context(0)
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libvwgpu.so loaded before torch must not leave the process with two HIP/HSA runtimes (the second
+    one finds no device).  Fresh interpreter: load the library, then import torch, then list the mapped
+    runtime libraries."""
+    import subprocess
+    import sys
+    code = (
+        "from vectorwave_amd import _native as N\n"
+        "N.load()\n"
+        "import torch\n"
+        "libs = set()\n"
+        "for line in open('/proc/self/maps'):\n"
+        "    p = line.split()[-1]\n"
+        "    if 'libamdhip64' in p or 'libhsa-runtime64' in p:\n"
+        "        libs.add(p)\n"
+        "names = sorted(libs)\n"
+        "assert len([p for p in names if 'libamdhip64' in p]) == 1, names\n"
+        "assert len([p for p in names if 'libhsa-runtime64' in p]) == 1, names\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -136,6 +136,7 @@ def test_single_level_bit_exact(ctx, wn, n, b, mode):
 @pytest.mark.parametrize("mode", [P, Z])
 @pytest.mark.parametrize("soft", [True, False])
 @pytest.mark.parametrize("wn,n,j,b,thr", [("db4", 480, 4, 64, -1.0), ("haar", 480, 4, 16, -1.0), ("db4", 256, 4, 8, -999.0),
+                                          ("bior4.4", 480, 4, 5, -1.0), ("db2", 31, 3, 7, -1.0), ("sym8", 1365, 4, 3, -1.0),
                                           ("db4", 481, 3, 8, -1.0), ("sym8", 4097, 5, 3, -1.0), ("db4", 9000, 6, 2, -1.0),
                                           ("db4", 480, 4, 8, 0.25), ("coif3", 1000, 3, 4, 0.0)])
 def test_swt_denoise_bit_exact(ctx, wn, n, j, b, thr, soft, mode):

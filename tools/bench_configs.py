@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Times every BASELINE configuration on one GPU through the device-pointer C ABI (inputs resident in
+HBM, HIP events on the launch stream) and prints one JSON object.  Not the headline bench (bench.py is);
+this is the per-configuration table quoted in DESIGN.md.
+
+usage: python tools/bench_configs.py [--steps K] [--warmup W] [--out file.json]
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import torch
+    from vectorwave_amd import _native as N
+    from util import dev_denoise, dev_forward, dev_inverse, dev_signals
+
+    ctx = N.Context(0)
+    stream = torch.cuda.current_stream()
+
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.steps
+
+    # (name, wavelet, rows, n, J, boundary, flags)
+    transforms = [
+        ("C1 db4 32x1000 single level", "db4", 32, 1000, 1, 0, N.VW_FLAG_SINGLE_LEVEL),
+        ("C2 haar 4096x65536 J=6", "haar", 4096, 65536, 6, 0, 0),
+        ("C2 db4 4096x65536 J=6", "db4", 4096, 65536, 6, 0, 0),
+        ("C3 sym8 64x777777 J=8 PERIODIC", "sym8", 64, 777777, 8, 0, 0),
+        ("C3 sym8 64x777777 J=8 ZERO_PADDING", "sym8", 64, 777777, 8, 1, 0),
+        ("C3 coif3 64x777777 J=8 PERIODIC", "coif3", 64, 777777, 8, 0, 0),
+        ("C3 db10 64x777777 J=8 PERIODIC", "db10", 64, 777777, 8, 0, 0),
+        ("C3 db10 64x777777 J=8 ZERO_PADDING", "db10", 64, 777777, 8, 1, 0),
+        ("C4 db4 65536x16384 J=6", "db4", 65536, 16384, 6, 0, 0),
+    ]
+    res = {}
+    for name, wn, rows, n, j, mode, flags in transforms:
+        if args.only and args.only not in name:
+            continue
+        x = dev_signals(rows, n, seed=1)
+        c = torch.empty((rows, j + 1, n), dtype=torch.float64, device=x.device)
+        xr = torch.empty_like(x)
+        f_ms = timed(lambda: dev_forward(ctx, x, wn, j, mode, flags, out=c))
+        i_ms = timed(lambda: dev_inverse(ctx, c, wn, mode, flags, out=xr))
+        samples = rows * n
+        bytes_dir = 8.0 * (j + 2) * samples
+        res[name] = {
+            "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
+            "fwd_inv_Gsamples_per_s": round(samples / ((f_ms + i_ms) * 1e-3) / 1e9, 3),
+            "forward_GBps": round(bytes_dir / (f_ms * 1e-3) / 1e9, 1),
+            "inverse_GBps": round(bytes_dir / (i_ms * 1e-3) / 1e9, 1),
+            "pct_of_hbm_roofline": round(100.0 * 2 * bytes_dir / ((f_ms + i_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 2),
+            "max_reconstruction_error": float((xr - x).abs().max()) if mode == 0 else None,
+        }
+        print(name, res[name], flush=True)
+        del x, c, xr
+        torch.cuda.empty_cache()
+
+    if not args.only or "C5" in args.only:
+        rows, n, j = 8192, 480, 4
+        x = dev_signals(rows, n, seed=5, noise=0.5)
+        y = torch.empty_like(x)
+        for wn in ("db4", "haar"):
+            d_ms = timed(lambda: dev_denoise(ctx, x, wn, j, 0, -1.0, True, out=y))
+            name = "C5 %s denoise 8192x480 J=4 universal soft" % wn
+            res[name] = {
+                "denoise_ms": round(d_ms, 4),
+                "Gsamples_per_s": round(rows * n / (d_ms * 1e-3) / 1e9, 3),
+                "blocks_per_s": round(rows / (d_ms * 1e-3)),
+                # algorithmic traffic of a denoise that keeps coefficients on chip: read x, write y
+                "algorithmic_GBps_16B_per_sample": round(16.0 * rows * n / (d_ms * 1e-3) / 1e9, 1),
+            }
+            print(name, res[name], flush=True)
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,30 @@ class NativeLibraryError(RuntimeError):
     """libvwgpu.so is missing or no GPU is usable.  Never swallowed: the package has no CPU path."""
 
 
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64
+    and ask for them by file name; libvwgpu.so asks for the soname.  If libvwgpu.so is loaded first it
+    binds the system runtime, torch then loads its bundled copy as a second runtime, and that one finds
+    no device.  When a torch installation is present its copies are therefore loaded first (without
+    importing torch), so both bind the same runtime whatever the import order.  Without torch (the Java
+    host) nothing happens and the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load libvwgpu.so and declare every prototype.  Raises NativeLibraryError if absent."""
     global _lib
@@ -95,6 +119,7 @@ def load():
         raise NativeLibraryError(
             "%s not found: build it with `make -C vectorwave_amd/csrc` (hipcc, gfx950). "
             "vectorwave_amd has no CPU fallback." % LIB_PATH)
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # missing HIP runtime etc.
