@@ -92,6 +92,44 @@ def test_streaming_runs_bit_exact(ctx, monkeypatch, wn, n, j, b, tile, wgs, mode
     assert st == N.VW_E_NONFINITE and bad == bad_at
 
 
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("chunks", [1, 3, 1000])
+@pytest.mark.parametrize("wn,n,j,b", [("sym8", 20000, 8, 2), ("db10", 30001, 8, 1), ("coif3", 12288, 7, 2), ("db20", 9000, 6, 2),
+                                      ("sym8", 3000, 7, 3), ("bior4.4", 10000, 8, 2)])
+def test_long_context_streaming_bit_exact(ctx, monkeypatch, wn, n, j, b, chunks, mode):
+    """Level groups whose context exceeds one chunk run the long-context streaming kernel: runs of tiles
+    warmed up by tiles computed with the stores off.  VW_SDRY_CHUNKS sets the run length: 1 (every tile
+    warms up on its own), 3 (runs start mid-row), 1000 (whole rows; the warm-up wraps around the row)."""
+    monkeypatch.setenv("VW_SDRY_CHUNKS", str(chunks))
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=n + j + chunks)
+    st, want = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    st, got, _ = gpu_forward(ctx, x, wn, j, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "long-context forward %s N=%d J=%d chunks=%d" % (wn, n, j, chunks))
+    if len(w.rec_hi) >= len(w.rec_lo):
+        wantx = o.reconstruct_batch(want, w, mode)
+        st, gotx, _ = gpu_inverse(ctx, want, wn, mode)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(gotx, wantx, "long-context inverse %s N=%d J=%d chunks=%d" % (wn, n, j, chunks))
+        st, wantd = o.swt_denoise_batch(x, w, j, -1.0, False, mode)
+        assert st == 0
+        st, gotd, _ = gpu_denoise(ctx, x, wn, j, mode, -1.0, False)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(gotd, wantd, "long-context denoise")
+        cb = want.copy()
+        bad_c = cb.size - n // 3
+        cb.reshape(-1)[bad_c] = np.nan
+        st, _, bad = gpu_inverse(ctx, cb, wn, mode, N.VW_FLAG_CHECK_FINITE)
+        assert st == N.VW_E_NONFINITE and bad == bad_c
+    xb = x.copy()
+    bad_at = (b - 1) * n + n // 2 + 1
+    xb.reshape(-1)[bad_at] = np.inf
+    st, _, bad = gpu_forward(ctx, xb, wn, j, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == bad_at
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("sym8", 4096, 5, 2), ("haar", 1000, 4, 4), ("bior4.4", 2000, 4, 2),
                                       ("db10", 9999, 8, 2), ("coif17", 4000, 5, 1)])

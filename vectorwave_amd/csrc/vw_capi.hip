@@ -252,6 +252,10 @@ struct Step {
     int lev0, lev1;
     bool fused;
     TileCfg cfg;
+    int sdry = 0;       // 0: tile kernels; 1, 2: dry-run-warmed streaming shapes (see plan_sdry)
+    int ndry = 0;       // warm-up tiles per run
+    int hist_cap = 0;   // doubles of history storage
+    int32_t hoff[kMaxLevels + 2] = {0}, hlen[kMaxLevels + 2] = {0};
 };
 
 static void scale_taps(const double* src, int len, double* dst) {
@@ -390,6 +394,100 @@ static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
     a->ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
 }
 
+// Long-context streaming (k_fwd_sdry / k_inv_sdry): shape 1 = 512 lanes, 2048-sample tiles, histories up to 2046
+// samples per level; shape 2 = 512 lanes, 4096-sample tiles, histories up to 2558.  Returns 0 if the
+// level group does not fit either.
+struct SdryShape {
+    int nt, ppt, hb;
+    int tile() const { return ppt * 2 * nt; }
+};
+static const SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
+
+static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, int32_t* hoff, int32_t* hlen, int* ndry,
+                     int* hist_cap) {
+    int64_t sum = 0, hmax = 0;
+    for (int j = lev0; j <= lev1; ++j) {
+        const int64_t hl = (static_cast<int64_t>(lmax - 1) * (static_cast<int64_t>(1) << (j - 1)) + 1) & ~static_cast<int64_t>(1);
+        if (hl > 4096) return 0;
+        hoff[j] = static_cast<int32_t>(sum);
+        hlen[j] = static_cast<int32_t>(hl);
+        sum += hl;
+        if (hl > hmax) hmax = hl;
+    }
+    if (getenv("VW_NO_SDRY") != nullptr) return 0;
+    for (int v = 1; v <= 2; ++v) {
+        const SdryShape& sh = kSdry[v];
+        const int64_t halo = static_cast<int64_t>(sh.hb) * kChunk;
+        if (hmax > halo - 2 || hmax > sh.tile()) continue;
+        const int64_t cap = (sum + 1023) / 1024 * 1024;
+        // forward: one buffer and one history; inverse: R and W buffers, R and W histories
+        const size_t lds = static_cast<size_t>(halo + sh.tile() + cap) * 8 * (inverse ? 2 : 1);
+        if (lds > static_cast<size_t>(lds_limit)) continue;
+        *ndry = static_cast<int>((sum + sh.tile() - 1) / sh.tile());
+        *hist_cap = static_cast<int>(cap);
+        return v;
+    }
+    return 0;
+}
+
+template <int NT, int P, int HB, int MODE>
+static hipError_t launch_fwd_sdry_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
+                         : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
+               : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
+}
+static hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
+                                  hipStream_t stream) {
+    const SdryShape& sh = kSdry[shape];
+    const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8;
+    if (shape == 1)
+        return mode == kPeriodic ? launch_fwd_sdry_pm<512, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
+                                 : launch_fwd_sdry_pm<512, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+    if (shape == 2)
+        return mode == kPeriodic ? launch_fwd_sdry_pm<512, 4, 5, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
+                                 : launch_fwd_sdry_pm<512, 4, 5, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+    return hipErrorInvalidValue;
+}
+
+template <int NT, int P, int HB, int MODE>
+static hipError_t launch_inv_sdry_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
+                         : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
+               : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
+}
+static hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
+                                  hipStream_t stream) {
+    const SdryShape& sh = kSdry[shape];
+    const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8 * 2;
+    if (shape == 1)
+        return mode == kPeriodic ? launch_inv_sdry_pm<512, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
+                                 : launch_inv_sdry_pm<512, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+    if (shape == 2)
+        return mode == kPeriodic ? launch_inv_sdry_pm<512, 4, 5, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
+                                 : launch_inv_sdry_pm<512, 4, 5, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+    return hipErrorInvalidValue;
+}
+
+// Run length of the long-context kernels: long enough to amortise the warm-up tiles, short enough to
+// fill the chip.  VW_SDRY_CHUNKS overrides (test / tuning hook).
+static void sdry_runs(int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out) {
+    int64_t nseg = rows > 0 ? (2048 + rows - 1) / rows : 1;
+    if (nseg > tiles) nseg = tiles;
+    if (nseg < 1) nseg = 1;
+    int64_t nch = (tiles + nseg - 1) / nseg;
+    const int64_t min_run = static_cast<int64_t>(ndry) * 6;
+    if (nch < min_run) nch = min_run < tiles ? min_run : tiles;
+    if (const char* e = getenv("VW_SDRY_CHUNKS")) {
+        const long v = atol(e);
+        if (v >= 1) nch = v < tiles ? v : tiles;
+    }
+    if (nch < 1) nch = 1;
+    *nchunks = static_cast<int32_t>(nch);
+    *nseg_out = static_cast<int32_t>((tiles + nch - 1) / nch);
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------------------
@@ -458,7 +556,17 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
 
     // ---- plan ----------------------------------------------------------------
     std::vector<Step> steps;
-    {
+    // a context beyond one chunk: all levels in one pass of the long-context streaming kernel if it fits
+    if (!generic_all && fwd_halo(1, levels, lh, lg, nullptr) + 2 > kChunk) {
+        Step st;
+        st.lev0 = 1;
+        st.lev1 = levels;
+        st.fused = true;
+        st.cfg = TileCfg{0, 0, kThreads};
+        st.sdry = plan_sdry(1, levels, lh > lg ? lh : lg, ctx->lds_limit, false, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
+        if (st.sdry != 0) steps.push_back(st);
+    }
+    if (steps.empty()) {
         int j = 1;
         while (j <= levels) {
             Step st;
@@ -504,7 +612,44 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
         const bool to_slot = ((nsteps - 1 - i) % 2) == 0;
         double* vout = to_slot ? aslot : wsp;
         const int64_t vstride = to_slot ? rowc : n;
-        if (st.fused) {
+        if (st.sdry != 0) {
+            FwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = in;
+            a.in_stride = in_stride;
+            a.wout = coeffs;
+            a.w_row_stride = rowc;
+            a.w_band_stride = band;
+            a.vout = vout;
+            a.v_stride = vstride;
+            a.n = n;
+            a.n_store = n;
+            a.nrows = b;
+            a.lev0 = st.lev0;
+            a.lev1 = st.lev1;
+            a.lh = lh;
+            a.lg = lg;
+            a.ndry = st.ndry;
+            a.hist_cap = st.hist_cap;
+            memcpy(a.hoff, st.hoff, sizeof(a.hoff));
+            memcpy(a.hlen, st.hlen, sizeof(a.hlen));
+            const int T = kSdry[st.sdry].tile();
+            const int64_t tiles = (n + T - 1) / T;
+            a.tiles_per_row = static_cast<int32_t>(tiles);
+            sdry_runs(b, tiles, st.ndry, &a.nchunks, &a.ntiles);
+            a.first_bad = first ? first_bad_cell : nullptr;
+            a.taps = taps;
+            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
+                if (strstr(dbg, "nostore")) a.n_store = 0;
+                if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
+            }
+            const bool vec2 = (n % 2 == 0) && (in_stride % 2 == 0) && (vstride % 2 == 0) && aligned16(in) &&
+                              aligned16(coeffs) && aligned16(vout);
+            const int64_t nblocks = b * a.ntiles;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            hipError_t e = launch_fwd_sdry(a, st.sdry, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
+        } else if (st.fused) {
             FwdArgs a;
             memset(&a, 0, sizeof(a));
             a.in = in;
@@ -695,6 +840,20 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             st.lev1 = j;
             st.fused = false;
             st.cfg = TileCfg{0, 0, kThreads};
+            // a context beyond one chunk: as many of the remaining levels as fit one pass of the
+            // long-context streaming kernel
+            if (!generic_all && inv_halo(1, j, lhr) + 2 > kChunk) {
+                for (int lo = 1; lo <= j && st.sdry == 0; ++lo) {
+                    st.sdry = plan_sdry(lo, j, lhr, ctx->lds_limit, true, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
+                    if (st.sdry != 0) st.lev0 = lo;
+                }
+                if (st.sdry != 0) {
+                    st.fused = true;
+                    steps.push_back(st);
+                    j = st.lev0 - 1;
+                    continue;
+                }
+            }
             if (!generic_all) {
                 TileCfg cfg;
                 if (pick_cfg(n, inv_halo(j, j, lhr), ctx->lds_limit, inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg)) {
@@ -732,7 +891,46 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
         const bool to_out = ((nsteps - 1 - i) % 2) == 0;
         double* rout = to_out ? xout : wsp;
         const int64_t rstride = n;
-        if (st.fused) {
+        if (st.sdry != 0) {
+            InvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rin = rin;
+            a.rin_stride = rin_stride;
+            a.win = coeffs;
+            a.w_row_stride = rowc;
+            a.w_band_stride = band;
+            a.rout = rout;
+            a.rout_stride = rstride;
+            a.n = n;
+            a.n_store = n;
+            a.nrows = b;
+            a.lev0 = st.lev0;
+            a.lev1 = st.lev1;
+            a.lh = lhr;
+            a.ndry = st.ndry;
+            a.hist_cap = st.hist_cap;
+            memcpy(a.hoff, st.hoff, sizeof(a.hoff));
+            memcpy(a.hlen, st.hlen, sizeof(a.hlen));
+            const int T = kSdry[st.sdry].tile();
+            const int64_t tiles = (n + T - 1) / T;
+            a.tiles_per_row = static_cast<int32_t>(tiles);
+            sdry_runs(b, tiles, st.ndry, &a.nchunks, &a.ntiles);
+            a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
+            a.thr_mode = thr_mode;
+            a.thr = thr_rows;
+            a.first_bad = first_bad_cell;
+            a.check_rin = first ? 1 : 0;
+            a.taps = taps;
+            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
+                if (strstr(dbg, "nostore")) a.n_store = 0;
+                if (strstr(dbg, "nocompute")) a.lh = 0;
+            }
+            const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
+            const int64_t nblocks = b * a.ntiles;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            hipError_t e = launch_inv_sdry(a, st.sdry, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(e));
+        } else if (st.fused) {
             InvArgs a;
             memset(&a, 0, sizeof(a));
             a.rin = rin;

@@ -56,6 +56,7 @@ struct FwdArgs {
     // last hlen[j] samples of V_{j-1} (the left context level j needs) from tile to tile in LDS
     int32_t tiles_per_row, nchunks;
     int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
+    int32_t ndry, hist_cap;  // k_fwd_sdry: warm-up tiles per run, doubles of history storage
     unsigned long long* first_bad;   // nullptr = no finite check
     Taps taps;
 };
@@ -75,6 +76,10 @@ struct InvArgs {
     int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
     int32_t lh;            // loop bound (low-pass reconstruction length)
     int32_t pend[kMaxLevels + 1];    // R_{j} is valid on buffer positions [0, pend[j]) (even)
+    // k_inv_sdry only: runs of `nchunks` tiles walked right to left, `ndry` warm-up tiles, and the first
+    // hlen[j] samples of R_j and W_j carried from tile to tile (hist_cap doubles of storage each)
+    int32_t tiles_per_row, nchunks, ndry, hist_cap;
+    int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     uint32_t band_mask;    // bit (j-1): use W_j, else zeros; bit 31: use rin, else zeros
     int32_t thr_mode;      // 0 none, 1 soft, 2 hard: applied to W_j as it is loaded
     const double* thr;     // per-row threshold (thr_mode != 0)
@@ -217,11 +222,11 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
 // LT > 0: both filters have exactly LT taps; the tap loop is unrolled completely and the 2*LT tap
 // values are fetched in one go, so no scalar load (which shares its completion counter with the LDS
 // reads) sits inside the loop.  LT == 0: any lengths, one tap per iteration, taps fetched one ahead.
-template <int PPT, int HPT, bool S1, bool FMA, int CH = kChunk, int LT = 0>
+template <int PPT, int HPT, bool S1, bool FMA, int CH = kChunk, int LT = 0, int HOFF = HPT * kChunk>
 __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int s, int tid,
                                           double (&av)[PPT][2], double (&aw)[PPT][2],
                                           double (&ah)[HPT][2], const int (&hbase)[HPT], const bool (&wact)[HPT]) {
-    constexpr int HALO = HPT * kChunk;
+    constexpr int HALO = HOFF;  // buffer position of the tile
     const int baseT = (HALO + 2 * tid) * 8;
     double xp[PPT], xph[HPT];
     if (S1) {
@@ -607,6 +612,160 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// streaming forward for long contexts (long filters, deep cascades)
+// ---------------------------------------------------------------------------
+//
+// Same run-of-tiles scheme as k_fwd_stream, for level groups whose context (L-1)(2^J-1) runs to
+// thousands of samples.  Recomputing such a halo per tile costs more than the tile itself, and holding
+// it in registers costs the occupancy; here nothing is recomputed per tile and the first tile of a run
+// is not special either: the run simply starts `ndry` tiles early with the stores switched off.  The
+// cascade is FIR, so after sum_j (L-1) 2^(j-1) samples every history holds exact values, whatever it
+// held before.  Histories: hlen[j] <= min(T, HB*512) samples of V_{j-1} per level in LDS.
+template <int NT, int PPT, int HB, int MODE, bool VEC2, bool FMA>
+__global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int HALO = HB * kChunk;
+    constexpr int CH = 2 * NT;
+    constexpr int T = PPT * CH;
+    constexpr int M = HALO + T;
+    double* buf = reinterpret_cast<double*>(vw_smem);
+    double* hst = buf + M;  // a.hist_cap doubles
+    const int tid = threadIdx.x;
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int seg = static_cast<int>(id - row * a.ntiles);
+    const int tile0 = seg * a.nchunks;
+    int ntl = a.tiles_per_row - tile0;
+    if (ntl > a.nchunks) ntl = a.nchunks;
+    const int64_t n = a.n;
+    const int64_t ns = a.n_store;
+    const double* __restrict__ inrow = a.in + row * a.in_stride;
+    // left of a ZERO_PADDING row everything is zero at every level: zeroed histories are already exact
+    const int ndry = (MODE == kZeroPad && tile0 == 0) ? 0 : a.ndry;
+
+    for (int i = 2 * tid; i < a.hist_cap; i += 2 * NT) *reinterpret_cast<double2*>(hst + i) = make_double2(0.0, 0.0);
+    lds_barrier();
+
+    // tile loader for any position: wraps (PERIODIC) or zero-fills (ZERO_PADDING) left of the row,
+    // zero-fills right of it
+    auto load_tile = [&](int64_t t0, double2(&v)[PPT]) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t t = t0 + k * CH + 2 * tid;
+            double2 x = make_double2(0.0, 0.0);
+            if (t >= 0) {
+                if (VEC2) {
+                    if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
+                } else {
+                    if (t < n) x.x = inrow[t];
+                    if (t + 1 < n) x.y = inrow[t + 1];
+                }
+            } else if (MODE == kPeriodic) {
+                if (VEC2) {
+                    x = *reinterpret_cast<const double2*>(inrow + mod_wrap(t, n));
+                } else {
+                    x.x = inrow[mod_wrap(t, n)];
+                    x.y = inrow[mod_wrap(t + 1, n)];
+                }
+            }
+            v[k] = x;
+        }
+    };
+    // the lanes that own the last hlen[j] samples of the tile swap them with the stored history, which
+    // becomes the left context of this tile
+    auto hist_swap = [&](int j, const double2(&vals)[PPT]) {
+        const int hl = a.hlen[j];
+        double* h0 = hst + a.hoff[j];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = k * CH + 2 * tid - (T - hl);
+            if (i >= 0) {
+                double2* h = reinterpret_cast<double2*>(h0 + i);
+                const double2 old = *h;
+                *h = vals[k];
+                *reinterpret_cast<double2*>(buf + HALO - hl + i) = old;
+            }
+        }
+    };
+
+    double2 pre[PPT];
+    for (int ch = -ndry; ch < ntl; ++ch) {
+        const int64_t t0 = static_cast<int64_t>(tile0 + ch) * T;
+        const bool dry = ch < 0;
+        if (ch == -ndry) load_tile(t0, pre);
+        if (a.first_bad != nullptr && !dry) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int64_t t = t0 + k * CH + 2 * tid;
+                if (t < n && !finite_f64(pre[k].x))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t));
+                if (t + 1 < n && !finite_f64(pre[k].y))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(row * n + t + 1));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) *reinterpret_cast<double2*>(buf + HALO + k * CH + 2 * tid) = pre[k];
+        hist_swap(a.lev0, pre);
+        lds_barrier();
+        if (ch + 1 < ntl) load_tile(t0 + T, pre);  // in flight while this tile is computed
+
+        for (int j = a.lev0; j <= a.lev1; ++j) {
+            const int s = 1 << (j - 1);
+            double av[PPT][2], aw[PPT][2], ah[1][2] = {{0.0, 0.0}};
+            const bool wact[1] = {false};
+            const int hbase[1] = {0};
+            const char* lds = reinterpret_cast<const char*>(buf);
+            if (s == 1)
+                fwd_level<PPT, 1, true, FMA, CH, 0, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
+            else
+                fwd_level<PPT, 1, false, FMA, CH, 0, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
+
+            if (!dry) {
+                double* __restrict__ wrow =
+                    a.wout + row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int64_t t = t0 + k * CH + 2 * tid;
+                    if (VEC2) {
+                        if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                    } else {
+                        if (t < ns) wrow[t] = aw[k][0];
+                        if (t + 1 < ns) wrow[t + 1] = aw[k][1];
+                    }
+                }
+            }
+            if (j == a.lev1) {
+                if (!dry) {
+                    double* __restrict__ vrow = a.vout + row * a.v_stride;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int64_t t = t0 + k * CH + 2 * tid;
+                        if (VEC2) {
+                            if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                        } else {
+                            if (t < ns) vrow[t] = av[k][0];
+                            if (t + 1 < ns) vrow[t + 1] = av[k][1];
+                        }
+                    }
+                }
+                if (ch + 1 < ntl) lds_barrier();  // last reads of this tile done before it is restaged
+            } else {
+                lds_barrier();  // every lane has finished reading V_{j-1}
+                double2 v2[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    v2[k] = make_double2(av[k][0], av[k][1]);
+                    *reinterpret_cast<double2*>(buf + HALO + k * CH + 2 * tid) = v2[k];
+                }
+                hist_swap(j + 1, v2);
+                lds_barrier();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fused inverse: levels lev1 down to lev0 of one (row, tile) per workgroup
 // ---------------------------------------------------------------------------
 //
@@ -823,6 +982,199 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
                 }
             }
             // the barrier at the top of the next iteration publishes R_{j-1}
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// streaming inverse for long contexts: mirror image of k_fwd_sdry
+// ---------------------------------------------------------------------------
+//
+// A workgroup walks a run of tiles of one row from right to left.  The right context of level j is the
+// head (first hlen[j] samples) of R_j and of the thresholded W_j of the tile processed just before,
+// kept in LDS; the run starts `ndry` tiles to the right of its last tile with the stores switched off,
+// after which every history is exact (FIR cascade).  While a level is computed, the next detail band
+// (or, at the last level, the next tile's R and first detail band) is in flight from HBM.
+template <int NT, int PPT, int HB, int MODE, bool VEC2, bool FMA>
+__global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int HALO = HB * kChunk;
+    constexpr int CH = 2 * NT;
+    constexpr int T = PPT * CH;
+    constexpr int M = T + HALO;
+    double* bufR = reinterpret_cast<double*>(vw_smem);
+    double* bufW = bufR + M;
+    double* hstR = bufW + M;           // a.hist_cap doubles
+    double* hstW = hstR + a.hist_cap;  // a.hist_cap doubles
+    const char* ldsR = reinterpret_cast<const char*>(bufR);
+    const char* ldsW = reinterpret_cast<const char*>(bufW);
+    const int tid = threadIdx.x;
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int seg = static_cast<int>(id - row * a.ntiles);
+    const int tile0 = seg * a.nchunks;
+    int ntl = a.tiles_per_row - tile0;
+    if (ntl > a.nchunks) ntl = a.nchunks;
+    const int64_t n = a.n;
+    const double* __restrict__ wbase = a.win + row * a.w_row_stride;
+    const double* __restrict__ rrow = a.rin + row * a.rin_stride;
+    const bool use_r = (a.band_mask >> 31) & 1u;
+    const double thr = (a.thr_mode != 0) ? a.thr[row] : 0.0;
+    // right of a ZERO_PADDING row everything is zero at every level: zeroed histories are already exact
+    const int ndry = (MODE == kZeroPad && tile0 + ntl == a.tiles_per_row) ? 0 : a.ndry;
+
+    for (int i = 2 * tid; i < 2 * a.hist_cap; i += 2 * NT) *reinterpret_cast<double2*>(hstR + i) = make_double2(0.0, 0.0);
+    lds_barrier();
+
+    // tile loader for any position: wraps (PERIODIC) or zero-fills (ZERO_PADDING) right of the row
+    auto load_tile = [&](const double* __restrict__ src, bool use, int64_t t0, double2(&v)[PPT]) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t t = t0 + k * CH + 2 * tid;
+            double2 x = make_double2(0.0, 0.0);
+            if (use) {
+                if (VEC2) {
+                    if (t < n)
+                        x = *reinterpret_cast<const double2*>(src + t);
+                    else if (MODE == kPeriodic)
+                        x = *reinterpret_cast<const double2*>(src + mod_wrap(t, n));
+                } else {
+                    if (t < n)
+                        x.x = src[t];
+                    else if (MODE == kPeriodic)
+                        x.x = src[mod_wrap(t, n)];
+                    if (t + 1 < n)
+                        x.y = src[t + 1];
+                    else if (MODE == kPeriodic)
+                        x.y = src[mod_wrap(t + 1, n)];
+                }
+            }
+            v[k] = x;
+        }
+    };
+    // the lanes that own the first hlen[j] samples of the tile swap them with the stored history, which
+    // becomes the right context of this tile
+    auto head_swap = [&](double* hst, double* buf, int j, const double2(&vals)[PPT]) {
+        const int hl = a.hlen[j];
+        double* h0 = hst + a.hoff[j];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = k * CH + 2 * tid;
+            if (i < hl) {
+                double2* h = reinterpret_cast<double2*>(h0 + i);
+                const double2 old = *h;
+                *h = vals[k];
+                *reinterpret_cast<double2*>(buf + T + i) = old;
+            }
+        }
+    };
+
+    bool wact[PPT];
+    int pb[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        wact[k] = true;
+        pb[k] = (k * CH + 2 * tid) * 8;
+    }
+    double2 pre[PPT];   // detail band on its way into bufW
+    double2 preR[PPT];  // R_{lev1} of the tile about to be staged
+    for (int ch = -ndry; ch < ntl; ++ch) {
+        const int64_t t0 = static_cast<int64_t>(tile0 + ntl - 1 - ch) * T;
+        const bool dry = ch < 0;
+        if (ch == -ndry) {
+            load_tile(rrow, use_r, t0, preR);
+            load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, (a.band_mask >> (a.lev1 - 1)) & 1u, t0, pre);
+        }
+        if (a.first_bad != nullptr && a.check_rin && !dry) {
+            const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
+#pragma unroll
+            for (int c = 0; c < PPT; ++c) {
+                const int64_t t = t0 + c * CH + 2 * tid;
+                if (t < n && !finite_f64(preR[c].x))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                if (t + 1 < n && !finite_f64(preR[c].y))
+                    atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PPT; ++c) *reinterpret_cast<double2*>(bufR + c * CH + 2 * tid) = preR[c];
+        head_swap(hstR, bufR, a.lev1, preR);
+
+        for (int j = a.lev1; j >= a.lev0; --j) {
+            const int s = 1 << (j - 1);
+            // ---- publish W_j (thresholded on the way in when denoising) ---------------
+#pragma unroll
+            for (int c = 0; c < PPT; ++c) {
+                double2 w = pre[c];
+                if (a.thr_mode != 0) {
+                    w.x = apply_thr(w.x, thr, a.thr_mode);
+                    w.y = apply_thr(w.y, thr, a.thr_mode);
+                }
+                if (a.first_bad != nullptr && !dry) {
+                    const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+                    const int64_t t = t0 + c * CH + 2 * tid;
+                    if (t < n && !finite_f64(w.x))
+                        atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                    if (t + 1 < n && !finite_f64(w.y))
+                        atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                }
+                pre[c] = w;
+                *reinterpret_cast<double2*>(bufW + c * CH + 2 * tid) = w;
+            }
+            head_swap(hstW, bufW, j, pre);
+            lds_barrier();  // R_j and W_j visible
+
+            // ---- loads that fly while this level is computed --------------------------
+            if (j > a.lev0) {
+                load_tile(wbase + static_cast<int64_t>(j - 2) * a.w_band_stride, (a.band_mask >> (j - 2)) & 1u, t0, pre);
+            } else if (ch + 1 < ntl) {
+                load_tile(rrow, use_r, t0 - T, preR);
+                load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, (a.band_mask >> (a.lev1 - 1)) & 1u,
+                          t0 - T, pre);
+            }
+
+            double acc[PPT][2];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k][0] = acc[k][1] = 0.0;
+            if (s == 1)
+                inv_level<PPT, PPT, true, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
+            else
+                inv_level<PPT, PPT, false, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
+
+            if (j == a.lev0) {
+                if (!dry) {
+                    double* __restrict__ orow = a.rout + row * a.rout_stride;
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) {
+                        const int64_t t = t0 + k * CH + 2 * tid;
+                        if (VEC2) {
+                            if (t < a.n_store)
+                                *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
+                        } else {
+                            if (t < a.n_store) orow[t] = acc[k][0];
+                            if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
+                        }
+                    }
+                }
+                if (ch + 1 < ntl) lds_barrier();  // last reads of this tile done before it is restaged
+            } else {
+                lds_barrier();  // every lane has finished reading R_j / W_j
+                double2 v2[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    v2[k] = make_double2(acc[k][0], acc[k][1]);
+                    if (MODE == kZeroPad) {
+                        // samples right of the signal are zero at every level
+                        const int64_t t = t0 + k * CH + 2 * tid;
+                        if (t >= n) v2[k].x = 0.0;
+                        if (t + 1 >= n) v2[k].y = 0.0;
+                    }
+                    *reinterpret_cast<double2*>(bufR + k * CH + 2 * tid) = v2[k];
+                }
+                head_swap(hstR, bufR, j - 1, v2);
+                // the barrier at the top of the next iteration publishes R_{j-1}
+            }
         }
     }
 }
