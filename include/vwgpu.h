@@ -57,6 +57,7 @@ typedef enum vw_status {
     VW_E_LENGTH_MISMATCH = 7, /* VAL_LENGTH_MISMATCH: filter lengths unusable           */
     VW_E_BOUNDARY = 103,      /* CFG_UNSUPPORTED_BOUNDARY_MODE                          */
     VW_E_LEVEL = 104,         /* CFG_INVALID_DECOMPOSITION_LEVEL                        */
+    VW_E_UNSUPPORTED = 105,   /* CFG_UNSUPPORTED_OPERATION: e.g. FIXED without a value  */
     VW_E_NO_DEVICE = 900,     /* no usable gfx950 device / HIP runtime failure          */
     VW_E_HIP = 901,           /* a HIP call failed; see vw_last_error                   */
     VW_E_NOMEM = 902,         /* device or host allocation failed                       */
@@ -219,6 +220,56 @@ int32_t vw_swt_denoise_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, in
                                  double *thresholds_out_dev, void *workspace_dev,
                                  size_t workspace_bytes, void *stream);
 size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
+
+/* ---- WaveletDenoiser --------------------------------------------------------- */
+
+/* Threshold selection methods of denoising/WaveletDenoiser.java:588-617. */
+typedef enum vw_threshold_method {
+    VW_THRESHOLD_UNIVERSAL = 0, /* sigma * sqrt(2 ln n)                          (:389-391) */
+    VW_THRESHOLD_SURE = 1,      /* min of Stein's risk over |c_k|, capped        (:432-483) */
+    VW_THRESHOLD_MINIMAX = 2,   /* piecewise in n                                (:488-499) */
+    VW_THRESHOLD_BAYES = 3,     /* sigma^2 / sqrt(max(var - sigma^2, 0) + 1e-10) (:512-539) */
+    VW_THRESHOLD_FIXED = 4      /* caller's value; single-level form only        (:350-360) */
+} vw_threshold_method;
+
+/* Batched WaveletDenoiser (denoising/WaveletDenoiser.java).
+ *   flags & VW_FLAG_SINGLE_LEVEL, levels == 1: denoise(signal, method, type) (:121-139), or
+ *     denoiseFixed(signal, fixed_threshold, type) (:350-360) when method == VW_THRESHOLD_FIXED:
+ *     MODWTTransform.forward, sigma = median(|d|)/0.6745, threshold the detail band,
+ *     MODWTTransform.inverse.
+ *   otherwise: denoiseMultiLevel(signal, levels, method, type) (:152-167, :179-227): sigma from
+ *     level 1, per level threshold = calculateThreshold(d_j, sigma / Math.sqrt(1 << (j-1)), method);
+ *     VW_THRESHOLD_FIXED is VW_E_UNSUPPORTED here, as calculateThreshold throws for it (:405-415).
+ *   soft != 0: SOFT, else HARD (:544-568).  log_n = Math.log(N) from the host's libm (negative: the
+ *   library computes it).  Mean, variance and SURE risks are summed in index order like the Java
+ *   loops, so thresholds and outputs are bit-identical to the scalar reference.  SURE costs O(N^2)
+ *   per band, as it does in the reference.
+ *   x [B][N] in, y [B][N] out (may alias x); thresholds_out (may be NULL) receives [B][levels].
+ *   The _dev variant takes a scratch block of vw_wavelet_denoise_workspace_bytes(...) or NULL/0 to let
+ *   the context allocate (and keep) one. */
+int32_t vw_wavelet_denoise_batch(vw_ctx *ctx, const double *x, int64_t b, int64_t n, int32_t levels,
+                                 const double *h, int32_t lh, const double *g, int32_t lg,
+                                 const double *hr, int32_t lhr, const double *gr, int32_t lgr,
+                                 int32_t boundary, uint32_t flags, int32_t method, int32_t soft,
+                                 double fixed_threshold, double log_n, double *y, double *thresholds_out);
+int32_t vw_wavelet_denoise_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
+                                     int32_t levels, const double *h, int32_t lh, const double *g,
+                                     int32_t lg, const double *hr, int32_t lhr, const double *gr,
+                                     int32_t lgr, int32_t boundary, uint32_t flags, int32_t method,
+                                     int32_t soft, double fixed_threshold, double log_n, double *y_dev,
+                                     double *thresholds_out_dev, void *workspace_dev,
+                                     size_t workspace_bytes, void *stream);
+size_t vw_wavelet_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
+
+/* WaveletDenoiser.calculateThreshold over a coefficient block [B][levels+1][N] (:385-427): sigma per
+ * row from band 0, thresholds [B][levels] out; level_scaled != 0 divides sigma by sqrt(1 << (j-1)). */
+int32_t vw_denoiser_thresholds_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n,
+                                     int32_t levels, int32_t method, int32_t level_scaled, double log_n,
+                                     double *thresholds);
+int32_t vw_denoiser_thresholds_batch_dev(vw_ctx *ctx, const double *coeffs_dev, int64_t b, int64_t n,
+                                         int32_t levels, int32_t method, int32_t level_scaled,
+                                         double log_n, double *thresholds_dev, double *sigma_scratch_dev,
+                                         void *stream);
 
 /* Per-signal universal threshold of an existing decomposition
  * (VectorWaveSwtAdapter.applyUniversalThreshold's threshold value,

@@ -144,6 +144,33 @@ def swt_denoise_batch(x, wavelet, levels, threshold=-1.0, soft=True, boundary=PE
     return int(st), out
 
 
+UNIVERSAL, SURE, MINIMAX, BAYES, FIXED = 0, 1, 2, 3, 4
+
+
+def denoiser_threshold(coeffs, sigma, method):
+    """WaveletDenoiser.calculateThreshold (denoising/WaveletDenoiser.java:385-427)."""
+    c = _f64(coeffs)
+    f = lib().vwo_denoiser_threshold
+    f.restype = C.c_double
+    return float(f(_p(c), C.c_int64(c.size), C.c_double(sigma), C.c_int(method)))
+
+
+def wavelet_denoise_batch(x, wavelet, levels, method, soft=True, boundary=PERIODIC, fixed_threshold=0.0):
+    """WaveletDenoiser.denoise / denoiseFixed (levels == 0) or denoiseMultiLevel (levels >= 1) per row.
+    Returns (status, denoised [B][N], thresholds [B][max(levels, 1)])."""
+    x = _f64(x)
+    b, n = x.shape
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    out = np.empty((b, n))
+    thr = np.empty((b, max(levels, 1)))
+    st = lib().vwo_wavelet_denoise_batch(_p(x), C.c_int64(b), C.c_int64(n), C.c_int(levels), _p(h), C.c_int(h.size),
+                                        _p(g), C.c_int(g.size), _p(hr), C.c_int(hr.size), _p(gr), C.c_int(gr.size),
+                                        C.c_int(boundary), C.c_int(method), C.c_double(fixed_threshold),
+                                        C.c_int(1 if soft else 0), _p(out), _p(thr))
+    return int(st), out, thr
+
+
 def apply_threshold(coeffs, threshold, soft):
     c = _f64(coeffs).copy()
     lib().vwo_apply_threshold(_p(c), C.c_int64(c.size), C.c_double(threshold), C.c_int(1 if soft else 0))

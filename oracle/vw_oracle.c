@@ -441,6 +441,162 @@ int vwo_swt_denoise(const double *x, int64_t n, int levels, const double *h, int
 }
 
 /* ------------------------------------------------------------------------ */
+/* denoising/WaveletDenoiser.java: threshold selection + single-/multi-level denoise */
+/* ------------------------------------------------------------------------ */
+
+/* denoising/WaveletDenoiser.java:468-483 (calculateSURERisk) */
+static double sure_risk(const double *coeffs, int64_t n, double threshold, double sigma) {
+    double sigma2 = sigma * sigma;
+    double risk = -(double)n * sigma2;
+    for (int64_t i = 0; i < n; i++) {
+        double c = coeffs[i];
+        double absC = fabs(c);
+        if (absC <= threshold) {
+            risk += c * c;
+        } else {
+            risk += sigma2 + (absC - threshold) * (absC - threshold);
+        }
+    }
+    return risk / (double)n;
+}
+
+/* denoising/WaveletDenoiser.java:385-427 (calculateThreshold) with :432-463 (SURE),
+ * :488-499 (MINIMAX), :512-539 (BAYES).  method: 0 UNIVERSAL, 1 SURE, 2 MINIMAX, 3 BAYES.
+ * Returns NaN for FIXED (4) and unknown methods, where the reference throws. */
+double vwo_denoiser_threshold(const double *coeffs, int64_t n, double sigma, int method) {
+    switch (method) {
+        case 0:
+            return sigma * sqrt(2.0 * log((double)n));
+        case 1: {
+            double *sorted = (double *)malloc(sizeof(double) * (size_t)n);
+            for (int64_t i = 0; i < n; i++) sorted[i] = fabs(coeffs[i]);
+            qsort(sorted, (size_t)n, sizeof(double), cmp_double);
+            double min_risk = INFINITY, best = 0;
+            for (int64_t k = 0; k < n; k++) {
+                double t = sorted[k];
+                double risk = sure_risk(coeffs, n, t, sigma);
+                if (risk < min_risk) {
+                    min_risk = risk;
+                    best = t;
+                }
+            }
+            free(sorted);
+            double universal = sigma * sqrt(2.0 * log((double)n));
+            if (best > universal) best = universal;
+            return best;
+        }
+        case 2: {
+            double logN = log((double)n);
+            if (n <= 32) return 0;
+            if (n <= 64) return sigma * 0.3936 + 0.1829 * sigma * logN;
+            return sigma * (0.4745 + 0.1148 * logN);
+        }
+        case 3: {
+            double sigma2 = sigma * sigma;
+            double mean = 0.0;
+            for (int64_t i = 0; i < n; i++) mean += coeffs[i];
+            mean /= (double)n;
+            double variance = 0.0;
+            for (int64_t i = 0; i < n; i++) {
+                double diff = coeffs[i] - mean;
+                variance += diff * diff;
+            }
+            variance /= (double)n;
+            double d = variance - sigma2;
+            double sigmaX2 = d > 0.0 ? d : 0.0; /* Math.max(0.0, variance - sigma2) for finite input */
+            double sigmaX = sqrt(sigmaX2 + 1e-10);
+            return sigma2 / sigmaX;
+        }
+        default:
+            return NAN;
+    }
+}
+
+/* denoising/WaveletDenoiser.java:544-568 (applyThreshold), out of place */
+static void denoiser_apply_threshold(const double *c, int64_t n, double threshold, int soft, double *out) {
+    if (soft)
+        vwo_soft_threshold(c, n, threshold, out);
+    else
+        vwo_hard_threshold(c, n, threshold, out);
+}
+
+/* denoising/WaveletDenoiser.java:121-139 (denoise) and :350-360 (denoiseFixed, method == 4):
+ * single-level MODWTTransform.forward -> threshold the detail band -> MODWTTransform.inverse */
+int vwo_wavelet_denoise(const double *x, int64_t n, const double *h, int lh, const double *g, int lg,
+                        const double *hr, int lhr, const double *gr, int lgr, int boundary, int method,
+                        double fixed_threshold, int soft, double *out, double *threshold_out) {
+    double *approx = (double *)malloc(sizeof(double) * (size_t)n * 3);
+    double *detail = approx + n, *den = detail + n;
+    vwo_modwt_forward(x, n, h, lh, g, lg, boundary, approx, detail);
+    double threshold;
+    if (method == 4) {
+        threshold = fixed_threshold;
+    } else {
+        double sigma = vwo_estimate_noise_sigma(detail, n);
+        threshold = vwo_denoiser_threshold(detail, n, sigma, method);
+    }
+    if (threshold_out) *threshold_out = threshold;
+    denoiser_apply_threshold(detail, n, threshold, soft, den);
+    vwo_modwt_inverse(approx, den, n, hr, lhr, gr, lgr, boundary, 0, out);
+    free(approx);
+    return 0;
+}
+
+/* denoising/WaveletDenoiser.java:152-167 + DenoisedMultiLevelResult :179-227: sigma from level 1,
+ * per level threshold = calculateThreshold(details_j, sigma / Math.sqrt(1 << (j-1)), method) */
+int vwo_wavelet_denoise_multilevel(const double *x, int64_t n, int levels, const double *h, int lh,
+                                   const double *g, int lg, const double *hr, int lhr, const double *gr,
+                                   int lgr, int boundary, int method, int soft, double *out,
+                                   double *thresholds_out /* [levels] or NULL */) {
+    double *coeffs = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(levels + 1));
+    int st = vwo_multilevel_decompose(x, n, levels, h, lh, g, lg, boundary, coeffs);
+    if (st != 0) {
+        free(coeffs);
+        return st;
+    }
+    double sigma = vwo_estimate_noise_sigma(coeffs, n);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int level = 1; level <= levels; level++) {
+        double *d = coeffs + (int64_t)(level - 1) * n;
+        double level_scale = sqrt((double)(1 << (level - 1)));
+        double threshold = vwo_denoiser_threshold(d, n, sigma / level_scale, method);
+        if (thresholds_out) thresholds_out[level - 1] = threshold;
+        denoiser_apply_threshold(d, n, threshold, soft, tmp);
+        memcpy(d, tmp, sizeof(double) * (size_t)n);
+    }
+    free(tmp);
+    vwo_multilevel_reconstruct(coeffs, n, levels, hr, lhr, gr, lgr, boundary, out);
+    free(coeffs);
+    return 0;
+}
+
+/* rows in parallel; levels == 0 selects the single-level form */
+int vwo_wavelet_denoise_batch(const double *x, int64_t b, int64_t n, int levels, const double *h, int lh,
+                              const double *g, int lg, const double *hr, int lhr, const double *gr,
+                              int lgr, int boundary, int method, double fixed_threshold, int soft,
+                              double *out, double *thresholds_out /* [b][max(levels,1)] or NULL */) {
+    int status = 0;
+    const int nl = levels > 0 ? levels : 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++) {
+        int st;
+        if (levels == 0)
+            st = vwo_wavelet_denoise(x + i * n, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, method,
+                                     fixed_threshold, soft, out + i * n,
+                                     thresholds_out ? thresholds_out + i * nl : NULL);
+        else
+            st = vwo_wavelet_denoise_multilevel(x + i * n, n, levels, h, lh, g, lg, hr, lhr, gr, lgr,
+                                                boundary, method, soft, out + i * n,
+                                                thresholds_out ? thresholds_out + i * nl : NULL);
+        if (st != 0) {
+#pragma omp critical
+            status = st;
+        }
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------------ */
 /* batch drivers (row loops, OpenMP over signals) used by tests + cpu_baseline */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,114 @@
+"""GPU parity of the WaveletDenoiser path (denoising/WaveletDenoiser.java) against the oracle: thresholds
+and denoised signals bit for bit, for every selection method, soft and hard, single- and multi-level,
+all three boundary modes; plus the Python mirror's error behaviour."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from vectorwave_amd import _native as N
+from vectorwave_amd import (BoundaryMode, InvalidArgumentException, InvalidSignalException, ThresholdMethod,
+                            ThresholdType, WaveletDenoiser)
+from vectorwave_amd.wavelets import get_wavelet
+
+from util import P, S, Z, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [o.UNIVERSAL, o.SURE, o.MINIMAX, o.BAYES]
+
+
+def _signals(b, n, seed, noise=0.3):
+    rng = np.random.default_rng(seed)
+    i = np.arange(n)
+    clean = np.sin(2 * np.pi * i / 32.0) + 0.5 * np.sin(4 * np.pi * i / 32.0)
+    return np.ascontiguousarray(clean[None] + noise * rng.standard_normal((b, n)))
+
+
+@pytest.mark.parametrize("mode", [P, Z, S])
+@pytest.mark.parametrize("soft", [True, False])
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("wn,n,levels,b", [("haar", 64, 0, 3), ("db4", 1000, 0, 4), ("db4", 1024, 5, 3), ("sym8", 5000, 6, 2),
+                                           ("haar", 33, 3, 2), ("bior4.4", 480, 4, 5), ("db4", 4100, 1, 2)])
+def test_denoiser_bit_exact(ctx, wn, n, levels, b, method, soft, mode):
+    w = get_wavelet(wn)
+    x = _signals(b, n, seed=n + levels + method)
+    st, want, want_thr = o.wavelet_denoise_batch(x, w, levels, method, soft, mode)
+    assert st == 0
+    den = WaveletDenoiser(w, BoundaryMode(mode), ctx)
+    got, thr = den.denoise_block(x, levels, method, ThresholdType.SOFT if soft else ThresholdType.HARD,
+                                 return_thresholds=True)
+    assert_bits_equal(thr, want_thr, "thresholds %s N=%d J=%d method=%d" % (wn, n, levels, method))
+    assert_bits_equal(got, want, "denoised %s N=%d J=%d method=%d" % (wn, n, levels, method))
+
+
+@pytest.mark.parametrize("soft", [True, False])
+def test_denoise_fixed_bit_exact(ctx, soft):
+    w = get_wavelet("db4")
+    x = _signals(6, 777, seed=5)
+    st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, soft, P, fixed_threshold=0.25)
+    den = WaveletDenoiser(w, BoundaryMode.PERIODIC, ctx)
+    for i in range(x.shape[0]):
+        got = den.denoiseFixed(x[i], 0.25, ThresholdType.SOFT if soft else ThresholdType.HARD)
+        assert_bits_equal(got, want[i], "denoiseFixed row %d" % i)
+
+
+def test_sure_on_a_band_longer_than_the_lds_stage(ctx):
+    # n > 4096: the SURE scan reads the band from global memory instead of LDS
+    w = get_wavelet("haar")
+    x = _signals(1, 5000, seed=9)
+    st, want, want_thr = o.wavelet_denoise_batch(x, w, 2, o.SURE, True, P)
+    got, thr = WaveletDenoiser(w, BoundaryMode.PERIODIC, ctx).denoise_block(x, 2, ThresholdMethod.SURE, return_thresholds=True)
+    assert_bits_equal(thr, want_thr, "SURE thresholds")
+    assert_bits_equal(got, want, "SURE denoised")
+
+
+def test_thresholds_entry_point(ctx):
+    w = get_wavelet("db4")
+    x = _signals(4, 2048, seed=2)
+    st, c = o.decompose_batch(x, w, 4, P)
+    for method in METHODS:
+        thr = np.empty((4, 4))
+        st = ctx.lib.vw_denoiser_thresholds_batch(ctx.handle, C.c_void_p(c.ctypes.data), 4, 2048, 4, method, 1,
+                                                  math.log(2048), C.c_void_p(thr.ctypes.data))
+        assert st == 0, ctx.last_error()
+        for r in range(4):
+            sigma = o.estimate_noise_sigma(c[r, 0])
+            for j in range(1, 5):
+                want = o.denoiser_threshold(c[r, j - 1], sigma / math.sqrt(1 << (j - 1)), method)
+                assert thr[r, j - 1] == want, (method, r, j)
+    st = ctx.lib.vw_denoiser_thresholds_batch(ctx.handle, C.c_void_p(c.ctypes.data), 4, 2048, 4, N.VW_THRESHOLD_FIXED, 1,
+                                              math.log(2048), C.c_void_p(thr.ctypes.data))
+    assert st == N.VW_E_UNSUPPORTED
+
+
+def test_mirror_api_and_errors(ctx):
+    den = WaveletDenoiser.forFinancialData(ctx)
+    assert den.wavelet.name == "db4" and den.boundaryMode == BoundaryMode.PERIODIC
+    x = _signals(1, 256, seed=1)[0]
+    # WaveletDenoiserBayesTest.java:200-214: a zero signal stays zero
+    z = WaveletDenoiser("haar", BoundaryMode.PERIODIC, ctx).denoise(np.zeros(16), ThresholdMethod.BAYES)
+    assert np.abs(z).max() <= 1e-6
+    # denoise(signal, method) defaults to SOFT (:108-110)
+    a = den.denoise(x, ThresholdMethod.UNIVERSAL)
+    b = den.denoise(x, ThresholdMethod.UNIVERSAL, ThresholdType.SOFT)
+    assert np.array_equal(a, b)
+    with pytest.raises(InvalidArgumentException):  # calculateThreshold throws for FIXED (:405-415)
+        den.denoise(x, ThresholdMethod.FIXED)
+    with pytest.raises(InvalidArgumentException):
+        den.denoiseMultiLevel(x, 3, ThresholdMethod.FIXED, ThresholdType.SOFT)
+    with pytest.raises(InvalidArgumentException):  # level limit of MultiLevelMODWTTransform.decompose
+        den.denoiseMultiLevel(x, 9, ThresholdMethod.UNIVERSAL, ThresholdType.SOFT)
+    with pytest.raises(InvalidSignalException):
+        den.denoise(np.array([1.0, np.nan, 2.0, 3.0]), ThresholdMethod.UNIVERSAL)
+    with pytest.raises(InvalidSignalException):
+        den.denoise(np.array([]), ThresholdMethod.UNIVERSAL)
+    with pytest.raises(InvalidArgumentException):
+        WaveletDenoiser(None, BoundaryMode.PERIODIC)
+    # batch surfaces agree with the per-signal calls
+    xs = _signals(5, 512, seed=4)
+    yb = den.denoiseMultiLevelBatch(xs, 4, ThresholdMethod.BAYES, ThresholdType.HARD)
+    for i in range(5):
+        assert np.array_equal(yb[i], den.denoiseMultiLevel(xs[i], 4, ThresholdMethod.BAYES, ThresholdType.HARD))

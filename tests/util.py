@@ -125,6 +125,26 @@ def dev_denoise(ctx, x_t, wname, levels, boundary, threshold, soft, out=None):
     return out, thr
 
 
+def dev_wavelet_denoise(ctx, x_t, wname, levels, boundary, method, soft, out=None, fixed_threshold=0.0):
+    """WaveletDenoiser on device-resident rows; levels == 0 selects the single-level form."""
+    import torch
+    w = get_wavelet(wname)
+    h, g, hr, gr = _t(w.dec_lo), _t(w.dec_hi), _t(w.rec_lo), _t(w.rec_hi)
+    b, n = x_t.shape
+    nl = max(levels, 1)
+    if out is None:
+        out = torch.empty((b, n), dtype=torch.float64, device=x_t.device)
+    thr = torch.empty((b, nl), dtype=torch.float64, device=x_t.device)
+    sp = C.c_void_p(torch.cuda.current_stream(x_t.device).cuda_stream)
+    flags = N.VW_FLAG_SINGLE_LEVEL if levels == 0 else 0
+    st = ctx.lib.vw_wavelet_denoise_batch_dev(ctx.handle, C.c_void_p(x_t.data_ptr()), b, n, nl, _dp(h), h.size, _dp(g),
+                                              g.size, _dp(hr), hr.size, _dp(gr), gr.size, boundary, flags, method,
+                                              1 if soft else 0, float(fixed_threshold), math.log(n),
+                                              C.c_void_p(out.data_ptr()), C.c_void_p(thr.data_ptr()), None, 0, sp)
+    assert st == 0, ctx.last_error()
+    return out, thr
+
+
 def dev_signals(b, n, seed=42, device="cuda:0", noise=0.1):
     import torch
     g = torch.Generator(device=device)

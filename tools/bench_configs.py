@@ -28,7 +28,7 @@ def main():
     args = ap.parse_args()
     import torch
     from vectorwave_amd import _native as N
-    from util import dev_denoise, dev_forward, dev_inverse, dev_signals
+    from util import dev_denoise, dev_forward, dev_inverse, dev_signals, dev_wavelet_denoise
 
     ctx = N.Context(0)
     stream = torch.cuda.current_stream()
@@ -95,6 +95,19 @@ def main():
                 "algorithmic_GBps_16B_per_sample": round(16.0 * rows * n / (d_ms * 1e-3) / 1e9, 1),
             }
             print(name, res[name], flush=True)
+    # WaveletDenoiser (the first "next" row): multi-level denoise with level-scaled thresholds
+    if not args.only or "N1" in args.only:
+        names = {0: "UNIVERSAL", 1: "SURE", 2: "MINIMAX", 3: "BAYES"}
+        for rows, n, j, methods in ((16384, 16384, 6, (0, 2, 3)), (8192, 480, 4, (0, 1, 2, 3))):
+            x = dev_signals(rows, n, seed=6, noise=0.3)
+            y = torch.empty_like(x)
+            for m in methods:
+                d_ms = timed(lambda: dev_wavelet_denoise(ctx, x, "db4", j, 0, m, True, out=y))
+                name = "N1 db4 WaveletDenoiser %dx%d J=%d %s soft" % (rows, n, j, names[m])
+                res[name] = {"denoise_ms": round(d_ms, 4), "Gsamples_per_s": round(rows * n / (d_ms * 1e-3) / 1e9, 3)}
+                print(name, res[name], flush=True)
+            del x, y
+            torch.cuda.empty_cache()
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)
 

@@ -6,11 +6,13 @@ behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
 from .api import (BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult, MODWTTransform,
                   MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult,
-                  VectorWaveSwtAdapter, WaveletOperations, WaveletTransformException)
+                  ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
+                  WaveletTransformException)
 from .wavelets import Wavelet, available_wavelets, get_wavelet
 
 __all__ = [
     "BoundaryMode", "InvalidArgumentException", "InvalidSignalException", "MODWTResult", "MODWTTransform",
     "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
+    "WaveletDenoiser", "ThresholdMethod", "ThresholdType",
 ]

@@ -23,6 +23,7 @@ VW_E_EMPTY = 6
 VW_E_LENGTH_MISMATCH = 7
 VW_E_BOUNDARY = 103
 VW_E_LEVEL = 104
+VW_E_UNSUPPORTED = 105
 VW_E_NO_DEVICE = 900
 VW_E_HIP = 901
 VW_E_NOMEM = 902
@@ -33,6 +34,12 @@ VW_FLAG_SYMMETRIC_BATCH_VARIANT = 2
 VW_FLAG_NO_LEVEL_CHECK = 4
 VW_FLAG_SINGLE_LEVEL = 8
 VW_FLAG_FMA = 16
+
+VW_THRESHOLD_UNIVERSAL = 0
+VW_THRESHOLD_SURE = 1
+VW_THRESHOLD_MINIMAX = 2
+VW_THRESHOLD_BAYES = 3
+VW_THRESHOLD_FIXED = 4
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
@@ -66,6 +73,17 @@ SIGNATURES = {
                                              _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                              C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "vw_swt_denoise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "vw_wavelet_denoise_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                             _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                             C.c_double, C.c_double, _vp, _vp]),
+    "vw_wavelet_denoise_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
+                                                 _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32,
+                                                 C.c_int32, C.c_double, C.c_double, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "vw_wavelet_denoise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "vw_denoiser_thresholds_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_double, _vp]),
+    "vw_denoiser_thresholds_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                                     C.c_double, _vp, _vp, _vp]),
     "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),
     "vw_swt_universal_threshold_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp,
                                                          _vp]),

@@ -61,6 +61,7 @@ _STATUS_TO_CODE = {
     N.VW_E_LENGTH_MISMATCH: "VAL_007",
     N.VW_E_BOUNDARY: "CFG_003",
     N.VW_E_LEVEL: "CFG_004",
+    N.VW_E_UNSUPPORTED: "CFG_005",
 }
 
 
@@ -72,7 +73,7 @@ def _raise_for_status(ctx: N.Context, st: int):
     code = _STATUS_TO_CODE.get(st)
     if st in (N.VW_E_NONFINITE, N.VW_E_EMPTY):
         raise InvalidSignalException(msg, code)
-    if st in (N.VW_E_LEVEL, N.VW_E_BOUNDARY, N.VW_E_TOO_LARGE):
+    if st in (N.VW_E_LEVEL, N.VW_E_BOUNDARY, N.VW_E_TOO_LARGE, N.VW_E_UNSUPPORTED):
         raise InvalidArgumentException(msg, code)
     if st == N.VW_E_NULL:
         raise TypeError(msg)  # NullPointerException
@@ -696,3 +697,104 @@ class VectorWaveSwtAdapter:
 
     def getCacheStatistics(self):
         return {"filterCacheSize": 0, "parallelExecutorActive": False, "parallelThreshold": self.PARALLEL_THRESHOLD}
+
+
+# ---------------------------------------------------------------------------
+# denoising/WaveletDenoiser.java
+# ---------------------------------------------------------------------------
+
+class ThresholdMethod(enum.IntEnum):
+    """denoising/WaveletDenoiser.java:588-617"""
+    UNIVERSAL = N.VW_THRESHOLD_UNIVERSAL
+    SURE = N.VW_THRESHOLD_SURE
+    MINIMAX = N.VW_THRESHOLD_MINIMAX
+    BAYES = N.VW_THRESHOLD_BAYES
+    FIXED = N.VW_THRESHOLD_FIXED
+
+
+class ThresholdType(enum.IntEnum):
+    """denoising/WaveletDenoiser.java:622-634"""
+    SOFT = 1
+    HARD = 0
+
+
+class WaveletDenoiser:
+    """Mirror of denoising/WaveletDenoiser.java: MAD noise estimate from the finest detail band, threshold
+    selection (UNIVERSAL, SURE, MINIMAX, BAYES), soft/hard thresholding, single- and multi-level forms.
+    Everything between the input and the output signal runs on the GPU in one downcall per batch."""
+
+    ThresholdMethod = ThresholdMethod
+    ThresholdType = ThresholdType
+
+    def __init__(self, wavelet, boundaryMode, ctx: Optional[N.Context] = None):
+        # :79-90
+        if wavelet is None:
+            raise InvalidArgumentException("wavelet cannot be null", "VAL_001")
+        if boundaryMode is None:
+            raise InvalidArgumentException("boundaryMode cannot be null", "VAL_001")
+        self.wavelet = _as_wavelet(wavelet)
+        self.boundaryMode = BoundaryMode(boundaryMode)
+        self._ctx = ctx
+
+    @property
+    def ctx(self) -> N.Context:
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    @staticmethod
+    def forFinancialData(ctx: Optional[N.Context] = None):
+        """:96-98: DB4, PERIODIC"""
+        return WaveletDenoiser("db4", BoundaryMode.PERIODIC, ctx)
+
+    def denoise_block(self, x: np.ndarray, levels: int, method, type=ThresholdType.SOFT, fixed_threshold: float = 0.0,
+                      return_thresholds: bool = False):
+        """x [B][N] -> denoised [B][N] (new batch surface).  levels == 0: the single-level form
+        (denoise / denoiseFixed); levels >= 1: denoiseMultiLevel."""
+        ctx = self.ctx
+        b, n = x.shape
+        w = self.wavelet
+        h, g, hr, gr = _taps(w.dec_lo), _taps(w.dec_hi), _taps(w.rec_lo), _taps(w.rec_hi)
+        nl = max(int(levels), 1)
+        out = np.empty((b, n))
+        thr = np.empty((b, nl))
+        flags = N.VW_FLAG_SINGLE_LEVEL if levels == 0 else 0
+        log_n = math.log(n) if n > 0 else 0.0
+        st = ctx.lib.vw_wavelet_denoise_batch(ctx.handle, _vp(x), b, n, nl, _dp(h), h.size, _dp(g), g.size, _dp(hr),
+                                              hr.size, _dp(gr), gr.size, int(self.boundaryMode), flags, int(method),
+                                              1 if int(type) == int(ThresholdType.SOFT) else 0, float(fixed_threshold),
+                                              log_n, _vp(out), _vp(thr))
+        _raise_for_status(ctx, st)
+        return (out, thr) if return_thresholds else out
+
+    def _checked(self, signal) -> np.ndarray:
+        # MODWTTransform.forward / MultiLevelMODWTTransform.decompose validate first (null, empty, finite)
+        x = _require_signal(signal)
+        if x.size == 0:
+            raise InvalidSignalException("Signal cannot be empty", "VAL_006")
+        bad = C.c_int64(-1)
+        _raise_for_status(self.ctx, self.ctx.lib.vw_first_non_finite(self.ctx.handle, _vp(x), x.size, C.byref(bad)))
+        return x
+
+    def denoise(self, signal, method, type=ThresholdType.SOFT):
+        """:108-139"""
+        x = self._checked(signal)
+        if int(method) == int(ThresholdMethod.FIXED):
+            raise InvalidArgumentException("Fixed threshold method requires explicit threshold value", "CFG_005")
+        return self.denoise_block(x.reshape(1, -1), 0, method, type)[0]
+
+    def denoiseMultiLevel(self, signal, levels, method, type):
+        """:152-167"""
+        x = self._checked(signal)
+        return self.denoise_block(x.reshape(1, -1), int(levels), method, type)[0]
+
+    def denoiseFixed(self, signal, threshold, type):
+        """:350-360"""
+        x = self._checked(signal)
+        return self.denoise_block(x.reshape(1, -1), 0, ThresholdMethod.FIXED, type, float(threshold))[0]
+
+    def denoiseBatch(self, signals, method, type=ThresholdType.SOFT):
+        return self.denoise_block(np.ascontiguousarray(np.asarray(signals, dtype=np.float64)), 0, method, type)
+
+    def denoiseMultiLevelBatch(self, signals, levels, method, type=ThresholdType.SOFT):
+        return self.denoise_block(np.ascontiguousarray(np.asarray(signals, dtype=np.float64)), int(levels), method, type)

@@ -813,7 +813,8 @@ extern "C" int32_t vw_modwt_forward_batch(vw_ctx* ctx, const double* x, int64_t 
 
 static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels, const double* hr, int lhr,
                        const double* gr, int lgr, int boundary, uint32_t flags, uint32_t band_mask, int thr_mode,
-                       const double* thr_rows, double* xout, unsigned long long* first_bad_cell, hipStream_t stream) {
+                       const double* thr_rows, double* xout, unsigned long long* first_bad_cell, hipStream_t stream,
+                       int64_t thr_row_stride = 1, int64_t thr_level_stride = 0) {
     Taps taps;
     scale_taps(hr, lhr, taps.lo);
     scale_taps(gr, lgr, taps.hi);
@@ -918,6 +919,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
             a.thr_mode = thr_mode;
             a.thr = thr_rows;
+            a.thr_row_stride = thr_row_stride;
+            a.thr_level_stride = thr_level_stride;
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
@@ -960,6 +963,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
             a.thr_mode = thr_mode;
             a.thr = thr_rows;
+            a.thr_row_stride = thr_row_stride;
+            a.thr_level_stride = thr_level_stride;
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
@@ -1249,15 +1254,15 @@ __global__ void __launch_bounds__(kThreads) k_fill(double* p, int64_t count, dou
 
 // thresholds every detail band of every row in place (generic-path denoise)
 __global__ void __launch_bounds__(kThreads) k_threshold_rows(double* coeffs, int64_t n, int levels,
-                                                             const double* __restrict__ thr, int mode) {
+                                                             const double* __restrict__ thr, int64_t thr_row_stride,
+                                                             int64_t thr_level_stride, int mode) {
     const int64_t row = blockIdx.y;
     const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
     const int64_t cnt = static_cast<int64_t>(levels) * n;
     double* p = coeffs + row * rowc;
-    const double t = thr[row];
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; i < cnt;
          i += static_cast<int64_t>(gridDim.x) * kThreads)
-        p[i] = apply_thr(p[i], t, mode);
+        p[i] = apply_thr(p[i], thr[row * thr_row_stride + (i / n) * thr_level_stride], mode);
 }
 
 extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
@@ -1314,7 +1319,7 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
         for (int64_t r0 = 0; r0 < b; r0 += 65535) {
             const int64_t nr = (b - r0) < 65535 ? (b - r0) : 65535;
             hipLaunchKernelGGL(k_threshold_rows, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nr)), dim3(kThreads), 0, s,
-                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0, mode);
+                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0, static_cast<int64_t>(1), static_cast<int64_t>(0), mode);
         }
         VW_HIP(ctx, hipGetLastError());
         return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, 0, 0xffffffffu, 0, nullptr, y_dev, nullptr, s);
@@ -1351,6 +1356,203 @@ extern "C" int32_t vw_swt_denoise_batch(vw_ctx* ctx, const double* x, int64_t b,
         VW_HIP(ctx, hipMemcpyAsync(y + r0 * n, dy, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
         if (thresholds_out != nullptr)
             VW_HIP(ctx, hipMemcpyAsync(thresholds_out + r0, dthr, static_cast<size_t>(nr) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// WaveletDenoiser
+// ---------------------------------------------------------------------------
+
+static size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+extern "C" size_t vw_wavelet_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels) {
+    if (b <= 0 || n <= 0 || levels < 1) return 0;
+    // coefficient block + per-row sigma + per-(row, level) thresholds
+    return round256(static_cast<size_t>(b) * static_cast<size_t>(levels + 1) * static_cast<size_t>(n) * 8) +
+           round256(static_cast<size_t>(b) * 8) + round256(static_cast<size_t>(b) * static_cast<size_t>(levels) * 8);
+}
+
+// sigma per row (MAD of band 0), then one workgroup per (row, level) selects the threshold
+static int denoiser_thresholds_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels, int method,
+                                   int level_scaled, double log_n, double* sigma, double* thr, hipStream_t s) {
+    if (method < VW_THRESHOLD_UNIVERSAL || method > VW_THRESHOLD_BAYES)
+        return set_err(ctx, VW_E_UNSUPPORTED, method == VW_THRESHOLD_FIXED
+                                                  ? "Fixed threshold method requires explicit threshold value"
+                                                  : "Unknown threshold selection method");
+    // sigma = median(|d_1|) / 0.6745: the universal-threshold kernel with a factor of exactly 1.0
+    int rc = universal_threshold_dev(ctx, coeffs, b, n, levels, 1.0, sigma, s);
+    if (rc != VW_OK) return rc;
+    DenoiserThrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.coeffs = coeffs;
+    a.row_stride = static_cast<int64_t>(levels + 1) * n;
+    a.band_stride = n;
+    a.n = n;
+    a.nrows = b;
+    a.levels = levels;
+    a.method = method;
+    a.level_scaled = level_scaled;
+    a.log_n = log_n < 0 ? log(static_cast<double>(n)) : log_n;
+    a.sigma = sigma;
+    a.thr = thr;
+    const int64_t nblocks = b * levels;
+    if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    if (method == VW_THRESHOLD_BAYES)
+        hipLaunchKernelGGL(k_denoiser_bayes, dim3(static_cast<unsigned>((nblocks + 63) / 64)), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_denoiser_thresholds, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_denoiser_thresholds_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n,
+                                                    int32_t levels, int32_t method, int32_t level_scaled, double log_n,
+                                                    double* thresholds_dev, double* sigma_scratch_dev, void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (b > 0 && (coeffs_dev == nullptr || thresholds_dev == nullptr || sigma_scratch_dev == nullptr))
+        return set_err(ctx, VW_E_NULL, "Result cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Signal cannot be empty");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    return denoiser_thresholds_dev(ctx, coeffs_dev, b, n, levels, method, level_scaled, log_n, sigma_scratch_dev,
+                                   thresholds_dev, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t vw_denoiser_thresholds_batch(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int32_t levels,
+                                                int32_t method, int32_t level_scaled, double log_n, double* thresholds) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (b > 0 && (coeffs == nullptr || thresholds == nullptr)) return set_err(ctx, VW_E_NULL, "Result cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Signal cannot be empty");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cbytes = static_cast<size_t>(b) * (levels + 1) * n * 8;
+    int rc = ensure(ctx, ctx->stage_in, cbytes);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, round256(static_cast<size_t>(b) * 8) + static_cast<size_t>(b) * levels * 8);
+    if (rc != VW_OK) return rc;
+    double* dc = static_cast<double*>(ctx->stage_in.p);
+    double* dsig = static_cast<double*>(ctx->stage_out.p);
+    double* dthr = reinterpret_cast<double*>(static_cast<char*>(ctx->stage_out.p) + round256(static_cast<size_t>(b) * 8));
+    VW_HIP(ctx, hipMemcpyAsync(dc, coeffs, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = denoiser_thresholds_dev(ctx, dc, b, n, levels, method, level_scaled, log_n, dsig, dthr, ctx->stream);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(thresholds, dthr, static_cast<size_t>(b) * levels * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
+                                                const double* h, int32_t lh, const double* g, int32_t lg,
+                                                const double* hr, int32_t lhr, const double* gr, int32_t lgr,
+                                                int32_t boundary, uint32_t flags, int32_t method, int32_t soft,
+                                                double fixed_threshold, double log_n, double* y_dev,
+                                                double* thresholds_out_dev, void* workspace_dev, size_t workspace_bytes,
+                                                void* stream) {
+    const uint32_t tflags = flags & (VW_FLAG_SINGLE_LEVEL | VW_FLAG_FMA);
+    const bool single = (tflags & VW_FLAG_SINGLE_LEVEL) != 0;
+    int rc = forward_checks(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, tflags, y_dev);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x_dev, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, y_dev);
+    if (rc != VW_OK) return rc;
+    if (method < VW_THRESHOLD_UNIVERSAL || method > VW_THRESHOLD_FIXED)
+        return set_err(ctx, VW_E_UNSUPPORTED, "Unknown threshold selection method");
+    if (method == VW_THRESHOLD_FIXED && !single)
+        return set_err(ctx, VW_E_UNSUPPORTED, "Fixed threshold method requires explicit threshold value");
+    if (b == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t need = vw_wavelet_denoise_workspace_bytes(b, n, levels);
+    char* wsb;
+    if (workspace_dev != nullptr) {
+        if (workspace_bytes < need) return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        wsb = static_cast<char*>(workspace_dev);
+    } else {
+        rc = ensure(ctx, ctx->denoise_ws, need);
+        if (rc != VW_OK) return rc;
+        wsb = static_cast<char*>(ctx->denoise_ws.p);
+    }
+    const size_t cbytes = round256(static_cast<size_t>(b) * (levels + 1) * n * 8);
+    double* coeffs = reinterpret_cast<double*>(wsb);
+    double* sigma = reinterpret_cast<double*>(wsb + cbytes);
+    double* thr = reinterpret_cast<double*>(wsb + cbytes + round256(static_cast<size_t>(b) * 8));
+
+    rc = forward_dev(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, tflags, coeffs, nullptr, s);
+    if (rc != VW_OK) return rc;
+    if (method == VW_THRESHOLD_FIXED) {
+        hipLaunchKernelGGL(k_fill, dim3(static_cast<unsigned>((b + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, thr, b,
+                           fixed_threshold);
+        VW_HIP(ctx, hipGetLastError());
+    } else {
+        rc = denoiser_thresholds_dev(ctx, coeffs, b, n, levels, method, single ? 0 : 1, log_n, sigma, thr, s);
+        if (rc != VW_OK) return rc;
+    }
+    if (thresholds_out_dev != nullptr)
+        VW_HIP(ctx, hipMemcpyAsync(thresholds_out_dev, thr, static_cast<size_t>(b) * levels * 8, hipMemcpyDeviceToDevice, s));
+    const int mode = soft ? 1 : 2;
+    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
+    if (!single) {
+        for (int j = 1; j <= levels; ++j) {
+            const int64_t st = static_cast<int64_t>(1) << (j - 1);
+            if (truncated_taps(lhr, st, n) != lhr || truncated_taps(lgr, st, n) != lgr) generic = true;
+        }
+    }
+    if (generic) {
+        const int64_t cnt = static_cast<int64_t>(levels) * n;
+        int64_t bx = (cnt + kThreads - 1) / kThreads;
+        if (bx > 1024) bx = 1024;
+        for (int64_t r0 = 0; r0 < b; r0 += 65535) {
+            const int64_t nr = (b - r0) < 65535 ? (b - r0) : 65535;
+            hipLaunchKernelGGL(k_threshold_rows, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nr)), dim3(kThreads), 0, s,
+                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0 * levels, static_cast<int64_t>(levels),
+                               static_cast<int64_t>(1), mode);
+        }
+        VW_HIP(ctx, hipGetLastError());
+        return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, 0, nullptr, y_dev,
+                           nullptr, s);
+    }
+    return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, mode, thr, y_dev, nullptr, s,
+                       levels, 1);
+}
+
+extern "C" int32_t vw_wavelet_denoise_batch(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int32_t levels,
+                                            const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
+                                            int32_t lhr, const double* gr, int32_t lgr, int32_t boundary, uint32_t flags,
+                                            int32_t method, int32_t soft, double fixed_threshold, double log_n, double* y,
+                                            double* thresholds_out) {
+    const uint32_t tflags = flags & (VW_FLAG_SINGLE_LEVEL | VW_FLAG_FMA);
+    int rc = forward_checks(ctx, x, b, n, levels, h, lh, g, lg, boundary, tflags, y);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, y);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = stage_rows(b, n, levels + 3);
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(rows) * n * 8);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, round256(static_cast<size_t>(rows) * n * 8) + static_cast<size_t>(rows) * levels * 8);
+    if (rc != VW_OK) return rc;
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* dy = static_cast<double*>(ctx->stage_out.p);
+    double* dthr = reinterpret_cast<double*>(static_cast<char*>(ctx->stage_out.p) + round256(static_cast<size_t>(rows) * n * 8));
+    for (int64_t r0 = 0; r0 < b; r0 += rows) {
+        const int64_t nr = (b - r0) < rows ? (b - r0) : rows;
+        VW_HIP(ctx, hipMemcpyAsync(dx, x + r0 * n, static_cast<size_t>(nr) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+        rc = vw_wavelet_denoise_batch_dev(ctx, dx, nr, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, flags, method, soft,
+                                          fixed_threshold, log_n, dy, thresholds_out != nullptr ? dthr : nullptr, nullptr, 0,
+                                          ctx->stream);
+        if (rc != VW_OK) return rc;
+        VW_HIP(ctx, hipMemcpyAsync(y + r0 * n, dy, static_cast<size_t>(nr) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (thresholds_out != nullptr)
+            VW_HIP(ctx, hipMemcpyAsync(thresholds_out + r0 * levels, dthr, static_cast<size_t>(nr) * levels * 8,
+                                       hipMemcpyDeviceToHost, ctx->stream));
         VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return VW_OK;

@@ -82,7 +82,8 @@ struct InvArgs {
     int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     uint32_t band_mask;    // bit (j-1): use W_j, else zeros; bit 31: use rin, else zeros
     int32_t thr_mode;      // 0 none, 1 soft, 2 hard: applied to W_j as it is loaded
-    const double* thr;     // per-row threshold (thr_mode != 0)
+    const double* thr;     // threshold of row r, level j at thr[r*thr_row_stride + (j-1)*thr_level_stride] (thr_mode != 0)
+    int64_t thr_row_stride, thr_level_stride;
     unsigned long long* first_bad;  // flat index into the coefficient block of the first NaN/Inf
     int32_t check_rin;     // rin is the a_J band of the block (top group): include it in the check
     Taps taps;
@@ -892,7 +893,6 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
     const int64_t t0 = static_cast<int64_t>(tile) * T;
     const int64_t n = a.n;
     const double* __restrict__ wbase = a.win + row * a.w_row_stride;
-    const double thr = (a.thr_mode != 0) ? a.thr[row] : 0.0;
 
     double2 pre[NP];
     // R_{lev1}
@@ -915,6 +915,7 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
 
     for (int j = a.lev1; j >= a.lev0; --j) {
         const int s = 1 << (j - 1);
+        const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
         // publish W_j (thresholded on the way in when denoising)
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
@@ -1020,7 +1021,6 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
     const double* __restrict__ wbase = a.win + row * a.w_row_stride;
     const double* __restrict__ rrow = a.rin + row * a.rin_stride;
     const bool use_r = (a.band_mask >> 31) & 1u;
-    const double thr = (a.thr_mode != 0) ? a.thr[row] : 0.0;
     // right of a ZERO_PADDING row everything is zero at every level: zeroed histories are already exact
     const int ndry = (MODE == kZeroPad && tile0 + ntl == a.tiles_per_row) ? 0 : a.ndry;
 
@@ -1103,6 +1103,7 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
 
         for (int j = a.lev1; j >= a.lev0; --j) {
             const int s = 1 << (j - 1);
+            const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
             // ---- publish W_j (thresholded on the way in when denoising) ---------------
 #pragma unroll
             for (int c = 0; c < PPT; ++c) {
@@ -1436,6 +1437,224 @@ __global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianAr
     if (tid == 0) {
         const double sigma = median / 0.6745;
         a.thr_out[row] = sigma * a.sqrt_2_ln_n;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// WaveletDenoiser threshold selection: one workgroup per (row, level)
+// ---------------------------------------------------------------------------
+//
+// UNIVERSAL and MINIMAX are closed forms of the row's sigma.  BAYES needs the mean and variance of the
+// band summed in index order (one lane adds, the others stage the band through LDS so that the adder
+// never waits for HBM).  SURE evaluates the risk of every candidate threshold |c_k| -- O(n^2) like the
+// reference -- one candidate per lane, each risk summed in index order, then the smallest risk (ties:
+// the smallest threshold, which is what scanning the sorted candidates for the first minimum yields).
+
+struct DenoiserThrArgs {
+    const double* coeffs;  // detail band j of row r at coeffs + r*row_stride + (j-1)*band_stride
+    int64_t row_stride, band_stride;
+    int64_t n;
+    int64_t nrows;
+    int32_t levels;
+    int32_t method;        // 0 UNIVERSAL, 1 SURE, 2 MINIMAX, 3 BAYES
+    int32_t level_scaled;  // 1: sigma_j = sigma / sqrt(1 << (j-1)) (multi-level form)
+    double log_n;          // Math.log(n), computed by the host
+    const double* sigma;   // [nrows] MAD estimate from the finest band
+    double* thr;           // [nrows][levels]
+};
+
+constexpr int kThrChunk = 4096;  // doubles of a band staged in LDS at a time
+
+__global__ void __launch_bounds__(kThreads) k_denoiser_thresholds(const DenoiserThrArgs a) {
+    __shared__ double stage[kThrChunk];
+    __shared__ double red_r[kThreads];
+    __shared__ double red_t[kThreads];
+    __shared__ double bc[2];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x / a.levels;
+    const int level = static_cast<int>(blockIdx.x - row * a.levels) + 1;
+    const int64_t n = a.n;
+    const double* __restrict__ c = a.coeffs + row * a.row_stride + static_cast<int64_t>(level - 1) * a.band_stride;
+    double sigma = a.sigma[row];
+    if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (level - 1)));
+    double* out = a.thr + row * a.levels + (level - 1);
+    const double universal = sigma * sqrt(2.0 * a.log_n);
+
+    if (a.method == 0) {
+        if (tid == 0) *out = universal;
+        return;
+    }
+    if (a.method == 2) {
+        if (tid == 0) {
+            double t;
+            if (n <= 32)
+                t = 0;
+            else if (n <= 64)
+                t = sigma * 0.3936 + 0.1829 * sigma * a.log_n;
+            else
+                t = sigma * (0.4745 + 0.1148 * a.log_n);
+            *out = t;
+        }
+        return;
+    }
+    if (a.method == 3) {
+        // pass 0: mean; pass 1: variance around it -- each a running sum in index order
+        double mean = 0.0, variance = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            double acc = 0.0;
+            for (int64_t base = 0; base < n; base += kThrChunk) {
+                const int cnt = static_cast<int>((n - base) < kThrChunk ? (n - base) : kThrChunk);
+                for (int i = tid; i < cnt; i += kThreads) stage[i] = c[base + i];
+                __syncthreads();
+                if (tid == 0) {
+                    if (pass == 0) {
+                        for (int i = 0; i < cnt; ++i) acc += stage[i];
+                    } else {
+                        for (int i = 0; i < cnt; ++i) {
+                            const double diff = stage[i] - mean;
+                            acc += diff * diff;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                if (pass == 0) {
+                    mean = acc / static_cast<double>(n);
+                    bc[0] = mean;
+                } else {
+                    variance = acc / static_cast<double>(n);
+                }
+            }
+            __syncthreads();
+            mean = bc[0];
+        }
+        if (tid == 0) {
+            const double sigma2 = sigma * sigma;
+            const double d = variance - sigma2;
+            const double sx2 = d > 0.0 ? d : 0.0;
+            const double sx = sqrt(sx2 + 1e-10);
+            *out = sigma2 / sx;
+        }
+        return;
+    }
+    // SURE
+    const double sigma2 = sigma * sigma;
+    double best_risk = __builtin_inf(), best_t = 0.0;
+    const bool in_lds = n <= kThrChunk;
+    if (in_lds) {
+        for (int i = tid; i < n; i += kThreads) stage[i] = c[i];
+        __syncthreads();
+    }
+    for (int64_t k = tid; k < n; k += kThreads) {
+        const double t = fabs(in_lds ? stage[k] : c[k]);
+        double risk = -static_cast<double>(n) * sigma2;
+        for (int64_t i = 0; i < n; ++i) {
+            const double v = in_lds ? stage[i] : c[i];
+            const double av = fabs(v);
+            if (av <= t) {
+                risk += v * v;
+            } else {
+                risk += sigma2 + (av - t) * (av - t);
+            }
+        }
+        risk = risk / static_cast<double>(n);
+        if (risk < best_risk || (risk == best_risk && t < best_t)) {
+            best_risk = risk;
+            best_t = t;
+        }
+    }
+    red_r[tid] = best_risk;
+    red_t[tid] = best_t;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (tid < w) {
+            const double r2 = red_r[tid + w], t2 = red_t[tid + w];
+            if (r2 < red_r[tid] || (r2 == red_r[tid] && t2 < red_t[tid])) {
+                red_r[tid] = r2;
+                red_t[tid] = t2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double best = red_t[0];
+        // the reference starts from minRisk = +inf, bestThreshold = 0: a band whose risks are all NaN or
+        // +inf keeps 0
+        if (!(red_r[0] < __builtin_inf())) best = 0.0;
+        if (best > universal) best = universal;
+        *out = best;
+    }
+}
+
+
+// BAYES thresholds, 64 bands per single-wave workgroup.  The mean and the variance must be running sums
+// in index order (that is what the Java loops round to), so a band is one dependent chain of adds; the
+// parallelism is across bands: every lane owns one (row, level) band and adds its elements in order,
+// while the wave loads the 64 bands' next 64 elements with coalesced 512-byte reads and transposes
+// them through LDS (row stride 65 doubles: conflict-free both ways).
+__global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) {
+    __shared__ double tile[64 * 65];
+    const int lane = threadIdx.x;
+    const int64_t nbands = a.nrows * a.levels;
+    const int64_t band0 = static_cast<int64_t>(blockIdx.x) * 64;
+    const int64_t n = a.n;
+    const int64_t mine = band0 + lane;
+    const bool have = mine < nbands;
+    const int64_t my_row = have ? mine / a.levels : 0;
+    const int my_level = have ? static_cast<int>(mine - my_row * a.levels) + 1 : 1;
+    const unsigned long long my_ptr = reinterpret_cast<unsigned long long>(
+        a.coeffs + my_row * a.row_stride + static_cast<int64_t>(my_level - 1) * a.band_stride);
+    const int nq = static_cast<int>((nbands - band0) < 64 ? (nbands - band0) : 64);
+    double mean = 0.0, variance = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0;
+        for (int64_t base = 0; base < n; base += 64) {
+            const int cnt = static_cast<int>((n - base) < 64 ? (n - base) : 64);
+            // wave-uniform loop over the 64 bands: lane = element index within the chunk; band q's base
+            // address lives in lane q
+            // 16 loads in flight at a time, then 16 LDS writes
+#pragma unroll
+            for (int q0 = 0; q0 < 64; q0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int q = q0 + u;
+                    const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(my_ptr & 0xffffffffu), q);
+                    const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(my_ptr >> 32), q);
+                    const double* __restrict__ c =
+                        reinterpret_cast<const double*>((static_cast<unsigned long long>(hi) << 32) | lo);
+                    v[u] = (q < nq && lane < cnt) ? c[base + lane] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tile[(q0 + u) * 65 + lane] = v[u];
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // one wave: no barrier needed
+            if (have) {
+                if (pass == 0) {
+                    for (int i = 0; i < cnt; ++i) acc += tile[lane * 65 + i];
+                } else {
+                    for (int i = 0; i < cnt; ++i) {
+                        const double diff = tile[lane * 65 + i] - mean;
+                        acc += diff * diff;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (pass == 0)
+            mean = acc / static_cast<double>(n);
+        else
+            variance = acc / static_cast<double>(n);
+    }
+    if (have) {
+        double sigma = a.sigma[my_row];
+        if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (my_level - 1)));
+        const double sigma2 = sigma * sigma;
+        const double d = variance - sigma2;
+        const double sx2 = d > 0.0 ? d : 0.0;
+        const double sx = sqrt(sx2 + 1e-10);
+        a.thr[my_row * a.levels + (my_level - 1)] = sigma2 / sx;
     }
 }
 
