@@ -146,6 +146,7 @@ class Context {
             case VW_E_LEVEL: throw InvalidArgumentException(msg, "CFG_004");
             case VW_E_BOUNDARY: throw InvalidArgumentException(msg, "CFG_003");
             case VW_E_TOO_LARGE: throw InvalidArgumentException(msg, "VAL_005");
+            case VW_E_UNSUPPORTED: throw InvalidArgumentException(msg, "CFG_005");
             case VW_E_NULL: throw NullPointerException(msg);
             case VW_E_NOT_POSITIVE: throw std::invalid_argument(msg);  // IllegalArgumentException
             case VW_E_LENGTH_MISMATCH: throw std::out_of_range(msg);  // ArrayIndexOutOfBoundsException
@@ -457,6 +458,59 @@ class VectorWaveSwtAdapter {
     BoundaryMode mode_;
     std::shared_ptr<Context> ctx_;
     MultiLevelMODWTTransform t_;
+};
+
+// ---- denoising/WaveletDenoiser.java ---------------------------------------------------------------
+class WaveletDenoiser {
+  public:
+    // :588-617, :622-634
+    enum class ThresholdMethod : int32_t { UNIVERSAL = VW_THRESHOLD_UNIVERSAL, SURE = VW_THRESHOLD_SURE, MINIMAX = VW_THRESHOLD_MINIMAX, BAYES = VW_THRESHOLD_BAYES, FIXED = VW_THRESHOLD_FIXED };
+    enum class ThresholdType : int32_t { SOFT = 1, HARD = 0 };
+
+    WaveletDenoiser(const Wavelet& wavelet, BoundaryMode mode, std::shared_ptr<Context> ctx = defaultContext()) : w_(wavelet), mode_(mode), ctx_(ctx) {}
+    // :96-98: DB4, PERIODIC
+    static WaveletDenoiser forFinancialData(std::shared_ptr<Context> ctx = defaultContext()) { return WaveletDenoiser(getWavelet("db4"), BoundaryMode::PERIODIC, ctx); }
+
+    // :108-139 (single-level MODWT, threshold from the detail band)
+    std::vector<double> denoise(const std::vector<double>& signal, ThresholdMethod method, ThresholdType type = ThresholdType::SOFT) const {
+        validate(signal);
+        if (method == ThresholdMethod::FIXED) throw InvalidArgumentException("Fixed threshold method requires explicit threshold value", "CFG_005");
+        return denoiseBlock(signal.data(), 1, static_cast<int64_t>(signal.size()), 0, method, type);
+    }
+    // :152-167 (J levels, sigma from level 1, threshold_j from sigma / sqrt(1 << (j-1)))
+    std::vector<double> denoiseMultiLevel(const std::vector<double>& signal, int levels, ThresholdMethod method, ThresholdType type) const {
+        validate(signal);
+        return denoiseBlock(signal.data(), 1, static_cast<int64_t>(signal.size()), levels, method, type);
+    }
+    // :350-360
+    std::vector<double> denoiseFixed(const std::vector<double>& signal, double threshold, ThresholdType type) const {
+        validate(signal);
+        return denoiseBlock(signal.data(), 1, static_cast<int64_t>(signal.size()), 0, ThresholdMethod::FIXED, type, threshold);
+    }
+    // x [B][N] -> y [B][N], one downcall; levels == 0 selects the single-level form; thresholds (optional) [B][max(levels,1)]
+    std::vector<double> denoiseBlock(const double* x, int64_t b, int64_t n, int levels, ThresholdMethod method, ThresholdType type,
+                                     double fixedThreshold = 0.0, std::vector<double>* thresholds = nullptr) const {
+        const int nl = levels > 0 ? levels : 1;
+        std::vector<double> y(static_cast<size_t>(b) * n);
+        if (thresholds != nullptr) thresholds->assign(static_cast<size_t>(b) * nl, 0.0);
+        ctx_->check(vw_wavelet_denoise_batch(ctx_->get(), x, b, n, nl, w_.decLo.data(), static_cast<int32_t>(w_.decLo.size()), w_.decHi.data(),
+                                             static_cast<int32_t>(w_.decHi.size()), w_.recLo.data(), static_cast<int32_t>(w_.recLo.size()), w_.recHi.data(),
+                                             static_cast<int32_t>(w_.recHi.size()), static_cast<int32_t>(mode_), levels == 0 ? VW_FLAG_SINGLE_LEVEL : 0u,
+                                             static_cast<int32_t>(method), type == ThresholdType::SOFT ? 1 : 0, fixedThreshold,
+                                             n > 0 ? std::log(static_cast<double>(n)) : 0.0, y.data(), thresholds != nullptr ? thresholds->data() : nullptr));
+        return y;
+    }
+
+  private:
+    // MODWTTransform.forward / MultiLevelMODWTTransform.decompose validate before transforming
+    void validate(const std::vector<double>& signal) const {
+        if (signal.empty()) throw InvalidSignalException("Signal cannot be empty", "VAL_006");
+        int64_t bad = -1;
+        ctx_->check(vw_first_non_finite(ctx_->get(), signal.data(), static_cast<int64_t>(signal.size()), &bad));
+    }
+    Wavelet w_;
+    BoundaryMode mode_;
+    std::shared_ptr<Context> ctx_;
 };
 
 }  // namespace vectorwave

@@ -59,6 +59,7 @@ public final class GpuModwtBackend implements AutoCloseable {
             case VwGpuNative.VW_E_LEVEL -> throw new InvalidArgumentException(ErrorCode.CFG_INVALID_DECOMPOSITION_LEVEL, msg);
             case VwGpuNative.VW_E_BOUNDARY -> throw new InvalidArgumentException(ErrorCode.CFG_UNSUPPORTED_BOUNDARY_MODE, msg);
             case VwGpuNative.VW_E_TOO_LARGE -> throw new InvalidArgumentException(ErrorCode.VAL_TOO_LARGE, msg);
+            case VwGpuNative.VW_E_UNSUPPORTED -> throw new InvalidArgumentException(ErrorCode.CFG_UNSUPPORTED_OPERATION, msg);
             case VwGpuNative.VW_E_NULL -> throw new NullPointerException(msg);
             case VwGpuNative.VW_E_NOT_POSITIVE -> throw new IllegalArgumentException(msg);
             case VwGpuNative.VW_E_LENGTH_MISMATCH -> throw new ArrayIndexOutOfBoundsException(msg);
@@ -119,6 +120,43 @@ public final class GpuModwtBackend implements AutoCloseable {
             check(st, bad.get(JAVA_LONG, 0));
             for (int i = 0; i < b; i++) {
                 MemorySegment.copy(x, JAVA_DOUBLE, (long) i * n * Double.BYTES, out[i], 0, n);
+            }
+            return out;
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /**
+     * WaveletDenoiser for a batch (denoising/WaveletDenoiser.java): levels == 0 is denoise()/denoiseFixed()
+     * (single-level transform), levels &gt;= 1 is denoiseMultiLevel().  method: ThresholdMethod.ordinal()
+     * (UNIVERSAL, SURE, MINIMAX, BAYES, FIXED).
+     */
+    public double[][] waveletDenoise(double[][] signals, Wavelet w, BoundaryMode mode, int levels, int method,
+                                     boolean soft, double fixedThreshold) {
+        int b = signals.length;
+        int n = b == 0 ? 0 : signals[0].length;
+        double[][] out = new double[b][n];
+        if (b == 0) {
+            return out;
+        }
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment x = pack(a, signals, n);
+            MemorySegment y = a.allocate(JAVA_DOUBLE, (long) b * n);
+            double[] h = w.lowPassDecomposition();
+            double[] g = w.highPassDecomposition();
+            double[] hr = w.lowPassReconstruction();
+            double[] gr = w.highPassReconstruction();
+            int flags = levels == 0 ? 8 /* VW_FLAG_SINGLE_LEVEL */ : 0;
+            // Math.log stays on the JVM so that the thresholds match the CPU path bit for bit
+            int st = (int) VwGpuNative.VW_WAVELET_DENOISE.invokeExact(ctx, x, (long) b, (long) n, Math.max(levels, 1),
+                taps(a, h), h.length, taps(a, g), g.length, taps(a, hr), hr.length, taps(a, gr), gr.length,
+                boundary(mode), flags, method, soft ? 1 : 0, fixedThreshold, Math.log(n), y, MemorySegment.NULL);
+            check(st, -1);
+            for (int i = 0; i < b; i++) {
+                MemorySegment.copy(y, JAVA_DOUBLE, (long) i * n * Double.BYTES, out[i], 0, n);
             }
             return out;
         } catch (RuntimeException e) {

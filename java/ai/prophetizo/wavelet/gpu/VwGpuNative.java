@@ -27,7 +27,7 @@ public final class VwGpuNative {
 
     // status codes (vw_status)
     public static final int VW_OK = 0, VW_E_NULL = 1, VW_E_NONFINITE = 3, VW_E_NOT_POSITIVE = 4, VW_E_TOO_LARGE = 5,
-        VW_E_EMPTY = 6, VW_E_LENGTH_MISMATCH = 7, VW_E_BOUNDARY = 103, VW_E_LEVEL = 104, VW_E_NO_DEVICE = 900;
+        VW_E_EMPTY = 6, VW_E_LENGTH_MISMATCH = 7, VW_E_BOUNDARY = 103, VW_E_LEVEL = 104, VW_E_UNSUPPORTED = 105, VW_E_NO_DEVICE = 900;
     // flags
     public static final int FLAG_CHECK_FINITE = 1, FLAG_SYMMETRIC_BATCH_VARIANT = 2, FLAG_NO_LEVEL_CHECK = 4,
         FLAG_SINGLE_LEVEL = 8;
@@ -60,6 +60,16 @@ public final class VwGpuNative {
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
             JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_DOUBLE, JAVA_DOUBLE, JAVA_INT, ADDRESS,
             ADDRESS));
+    // int32 vw_wavelet_denoise_batch(ctx, x, b, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, flags, method,
+    //                                soft, fixed_threshold, log_n, y, thresholds_out)
+    static final MethodHandle VW_WAVELET_DENOISE = h("vw_wavelet_denoise_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_DOUBLE,
+            JAVA_DOUBLE, ADDRESS, ADDRESS));
+    // int32 vw_denoiser_thresholds_batch(ctx, coeffs, b, n, levels, method, level_scaled, log_n, thresholds)
+    static final MethodHandle VW_DENOISER_THRESHOLDS = h("vw_denoiser_thresholds_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_INT, JAVA_INT,
+            JAVA_DOUBLE, ADDRESS));
     // int32 vw_swt_universal_threshold_batch(ctx, coeffs, b, n, levels, sqrt_2_ln_n, thresholds)
     static final MethodHandle VW_UNIVERSAL_THRESHOLD = h("vw_swt_universal_threshold_batch",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_DOUBLE, ADDRESS));

@@ -15,6 +15,8 @@ void vwo_multilevel_reconstruct_batch(const double*, int64_t, int64_t, int, cons
 int vwo_swt_denoise_batch(const double*, int64_t, int64_t, int, const double*, int, const double*, int, const double*, int, const double*,
                           int, int, double, int, double*);
 void vwo_modwt_forward_batch(const double*, int64_t, int64_t, const double*, int, const double*, int, int, double*);
+int vwo_wavelet_denoise_batch(const double*, int64_t, int64_t, int, const double*, int, const double*, int, const double*, int, const double*, int,
+                              int, int, double, int, double*, double*);
 }
 
 using namespace vectorwave;
@@ -134,6 +136,33 @@ int main() {
             for (int i = 0; i < 256; ++i) total[i] += e[i];
         }
         CHECK(max_abs_diff(total, x) < 1e-8);
+    }
+    {
+        // WaveletDenoiser: every selection method, single- and multi-level, against the oracle
+        const Wavelet& w = getWavelet("db4");
+        WaveletDenoiser d = WaveletDenoiser::forFinancialData();
+        auto x = make_signal(512, 7);
+        using M = WaveletDenoiser::ThresholdMethod;
+        using T = WaveletDenoiser::ThresholdType;
+        for (int method = 0; method < 4; ++method) {
+            std::vector<double> want(512), wthr(4);
+            CHECK(vwo_wavelet_denoise_batch(x.data(), 1, 512, 4, w.decLo.data(), 8, w.decHi.data(), 8, w.recLo.data(), 8, w.recHi.data(), 8, 0, method,
+                                            0.0, 0, want.data(), wthr.data()) == 0);
+            CHECK(bits_equal(d.denoiseMultiLevel(x, 4, static_cast<M>(method), T::HARD), want));
+            CHECK(vwo_wavelet_denoise_batch(x.data(), 1, 512, 0, w.decLo.data(), 8, w.decHi.data(), 8, w.recLo.data(), 8, w.recHi.data(), 8, 0, method,
+                                            0.0, 1, want.data(), wthr.data()) == 0);
+            CHECK(bits_equal(d.denoise(x, static_cast<M>(method)), want));
+        }
+        std::vector<double> want(512), wthr(1);
+        CHECK(vwo_wavelet_denoise_batch(x.data(), 1, 512, 0, w.decLo.data(), 8, w.decHi.data(), 8, w.recLo.data(), 8, w.recHi.data(), 8, 0, 4, 0.3, 1,
+                                        want.data(), wthr.data()) == 0);
+        CHECK(bits_equal(d.denoiseFixed(x, 0.3, T::SOFT), want));
+        bool threw = false;
+        try { d.denoise(x, M::FIXED); } catch (const InvalidArgumentException&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { d.denoiseMultiLevel(x, 3, M::FIXED, T::SOFT); } catch (const InvalidArgumentException&) { threw = true; }
+        CHECK(threw);
     }
     std::printf(failures == 0 ? "cpp mirror: all checks passed\n" : "cpp mirror: %d checks FAILED\n", failures);
     return failures == 0 ? 0 : 1;

@@ -98,3 +98,57 @@ def test_gpu_reference_kats(ctx):
     np.testing.assert_allclose(W.circularConvolveMODWT(e["signal"], e["filter"], None, ctx)[:2], e["expected_first_two"], rtol=0, atol=e["tol"])
     t = MultiLevelMODWTTransform("haar", BoundaryMode.PERIODIC, ctx)
     assert t.getMaximumLevels(10000) == 9 and MultiLevelMODWTTransform.getMaxDecompositionLevels() == 10
+
+
+# ---- second fixture: WaveletDenoiser and long-context level groups -------------------------------------
+
+def _extra():
+    z = np.load(os.path.join(GOLD, "denoiser_longcontext_vectors.npz"))
+    dn = []
+    for key in z["_denoiser_cases"]:
+        key = str(key)
+        wn, n, lv, m, s, mode = key.rsplit("_", 5)
+        dn.append((key, wn.replace("_", "."), int(n[1:]), int(lv[1:]), int(m[1:]), int(s[1:]), int(mode[1:])))
+    lc = []
+    for key in z["_long_context_cases"]:
+        key = str(key)
+        wn, n, j, mode = key.rsplit("_", 3)
+        lc.append((key, wn.replace("_", "."), int(n[1:]), int(j[1:]), int(mode[1:])))
+    return z, dn, lc
+
+
+def test_oracle_reproduces_extra_golden_vectors():
+    z, dn, lc = _extra()
+    assert len(dn) == 8 and len(lc) == 4
+    for key, wn, n, levels, method, soft, mode in dn:
+        st, y, thr = o.wavelet_denoise_batch(z[key + "_x"], get_wavelet(wn), levels, method, bool(soft), mode,
+                                             fixed_threshold=0.2)
+        assert st == 0
+        assert_bits_equal(thr, z[key + "_thr"], key + " thresholds")
+        assert_bits_equal(y, z[key + "_y"], key + " denoised")
+    for key, wn, n, j, mode in lc:
+        w = get_wavelet(wn)
+        st, c = o.decompose_batch(z[key + "_x"], w, j, mode)
+        assert st == 0
+        assert_bits_equal(c, z[key + "_coeffs"], key + " coeffs")
+        assert_bits_equal(o.reconstruct_batch(c, w, mode), z[key + "_recon"], key + " recon")
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_extra_golden_vectors(ctx):
+    from util import gpu_forward, gpu_inverse
+    from vectorwave_amd import BoundaryMode, ThresholdType, WaveletDenoiser
+    z, dn, lc = _extra()
+    for key, wn, n, levels, method, soft, mode in dn:
+        den = WaveletDenoiser(wn, BoundaryMode(mode), ctx)
+        y, thr = den.denoise_block(np.ascontiguousarray(z[key + "_x"]), levels, method,
+                                   ThresholdType.SOFT if soft else ThresholdType.HARD, 0.2, return_thresholds=True)
+        assert_bits_equal(thr, z[key + "_thr"], key + " thresholds")
+        assert_bits_equal(y, z[key + "_y"], key + " denoised")
+    for key, wn, n, j, mode in lc:
+        st, c, _ = gpu_forward(ctx, np.ascontiguousarray(z[key + "_x"]), wn, j, mode)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(c, z[key + "_coeffs"], key + " coeffs")
+        st, r, _ = gpu_inverse(ctx, np.ascontiguousarray(z[key + "_coeffs"]), wn, mode)
+        assert st == 0, ctx.last_error()
+        assert_bits_equal(r, z[key + "_recon"], key + " recon")

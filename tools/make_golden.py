@@ -100,6 +100,43 @@ def main():
     np.savez_compressed(os.path.join(OUT, "oracle_vectors.npz"), **arrays)
     sz = os.path.getsize(os.path.join(OUT, "oracle_vectors.npz"))
     print("wrote %d cases, %.1f KiB" % (len(names), sz / 1024))
+    make_extra()
+
+
+# second fixture: the WaveletDenoiser path and level groups with a long context (more than one
+# 512-sample chunk of history), which run different kernels from the cases above
+DENOISER_CASES = [  # wavelet, N, levels (0 = single-level form), method, soft, boundary
+    ("haar", 64, 0, 3, 1, 0), ("db4", 250, 0, 1, 0, 0), ("db4", 250, 0, 4, 1, 1), ("db4", 512, 4, 0, 1, 0),
+    ("db4", 512, 4, 1, 1, 0), ("db4", 512, 4, 2, 0, 1), ("db4", 512, 4, 3, 1, 2), ("sym8", 700, 3, 3, 0, 0),
+]
+LONG_CONTEXT_CASES = [("sym8", 1300, 6), ("db10", 1001, 5)]  # wavelet, N, J
+
+
+def make_extra():
+    arrays, dn, lc = {}, [], []
+    for wn, n, levels, method, soft, mode in DENOISER_CASES:
+        w = get_wavelet(wn)
+        x = signals(2, n, seed=2000 + n + levels + method)
+        key = "%s_N%d_L%d_M%d_S%d_m%d" % (wn.replace(".", "_"), n, levels, method, soft, mode)
+        st, y, thr = o.wavelet_denoise_batch(x, w, levels, method, bool(soft), mode, fixed_threshold=0.2)
+        assert st == 0, key
+        arrays[key + "_x"], arrays[key + "_y"], arrays[key + "_thr"] = x, y, thr
+        dn.append(key)
+    for wn, n, j in LONG_CONTEXT_CASES:
+        w = get_wavelet(wn)
+        x = signals(1, n, seed=3000 + n + j)
+        for mode in (0, 1):
+            key = "%s_N%d_J%d_m%d" % (wn.replace(".", "_"), n, j, mode)
+            st, c = o.decompose_batch(x, w, j, mode)
+            assert st == 0, key
+            arrays[key + "_x"], arrays[key + "_coeffs"] = x, c
+            arrays[key + "_recon"] = o.reconstruct_batch(c, w, mode)
+            lc.append(key)
+    arrays["_denoiser_cases"] = np.array(dn)
+    arrays["_long_context_cases"] = np.array(lc)
+    path = os.path.join(OUT, "denoiser_longcontext_vectors.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %d + %d extra cases, %.1f KiB" % (len(dn), len(lc), os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":
