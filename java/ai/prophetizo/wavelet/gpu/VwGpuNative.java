@@ -30,7 +30,7 @@ public final class VwGpuNative {
         VW_E_EMPTY = 6, VW_E_LENGTH_MISMATCH = 7, VW_E_BOUNDARY = 103, VW_E_LEVEL = 104, VW_E_UNSUPPORTED = 105, VW_E_NO_DEVICE = 900;
     // flags
     public static final int FLAG_CHECK_FINITE = 1, FLAG_SYMMETRIC_BATCH_VARIANT = 2, FLAG_NO_LEVEL_CHECK = 4,
-        FLAG_SINGLE_LEVEL = 8;
+        FLAG_SINGLE_LEVEL = 8, FLAG_FMA = 16;
 
     private static MethodHandle h(String name, FunctionDescriptor fd) {
         return LINKER.downcallHandle(LIB.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), fd);

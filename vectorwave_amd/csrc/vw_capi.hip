@@ -5,7 +5,8 @@
 // tile kernels, kernel-instance dispatch, staging for the host-pointer entry
 // points.  No CPU compute path exists here: without a HIP device every entry
 // point that would compute fails with VW_E_NO_DEVICE.
-#include "vw_kernels.hip.h"
+#include "vw_aux_kernels.hip.h"
+#include "vw_launch.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -153,18 +154,6 @@ extern "C" int32_t vw_max_levels(int64_t n, int32_t filter_len) {
 
 static constexpr int kHaloMaxChunks = 10;  // largest HPT instantiated
 
-struct TileCfg {
-    int ppt, hpt, nt;  // tile = ppt chunks of 2*nt samples, halo = hpt * 512 samples, nt lanes per workgroup
-    int tile() const { return ppt * 2 * nt; }
-    // forward shapes with a one-chunk halo run the tile-streaming kernel (one buffer + level histories);
-    // everything else runs the one-tile-per-workgroup kernels (two buffers)
-    size_t lds_bytes(bool inverse) const {
-        const size_t m = static_cast<size_t>(tile()) + static_cast<size_t>(hpt) * kChunk;
-        if (!inverse && hpt == 1) return (m + kChunk) * 8;
-        return 2 * m * 8;
-    }
-};
-
 // Instantiated shapes, each list in order of preference within one halo size (measured on MI355X, DB4
 // J=6, 65536 x 16384).  Keep in sync with the dispatch below.
 //   forward: 1024-sample tiles streamed along the row beat larger ones (more resident workgroups)
@@ -269,96 +258,6 @@ static void scale_taps(const double* src, int len, double* dst) {
 // kernel-instance dispatch
 // ---------------------------------------------------------------------------
 
-template <typename K, typename A>
-static hipError_t launch_tile(K kernel, const A& args, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), lds, stream, args);
-    return hipGetLastError();
-}
-
-template <typename K, typename A>
-static hipError_t launch_tile_nt(K kernel, const A& args, int nt, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nblocks)), dim3(nt), lds, stream, args);
-    return hipGetLastError();
-}
-
-template <int P, int H, int MODE>
-static hipError_t launch_fwd_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile(k_fwd_fused<P, H, MODE, true, true>, a, nblocks, lds, stream)
-                         : launch_tile(k_fwd_fused<P, H, MODE, true, false>, a, nblocks, lds, stream);
-    return fma ? launch_tile(k_fwd_fused<P, H, MODE, false, true>, a, nblocks, lds, stream)
-               : launch_tile(k_fwd_fused<P, H, MODE, false, false>, a, nblocks, lds, stream);
-}
-template <int P, int H, int MODE>
-static hipError_t launch_inv_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile(k_inv_fused<P, H, MODE, true, true>, a, nblocks, lds, stream)
-                         : launch_tile(k_inv_fused<P, H, MODE, true, false>, a, nblocks, lds, stream);
-    return fma ? launch_tile(k_inv_fused<P, H, MODE, false, true>, a, nblocks, lds, stream)
-               : launch_tile(k_inv_fused<P, H, MODE, false, false>, a, nblocks, lds, stream);
-}
-template <int NT, int P, int MODE, int LT>
-static hipError_t launch_fwd_stream_lt(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile_nt(k_fwd_stream<NT, P, MODE, true, true, LT>, a, NT, nblocks, lds, stream)
-                         : launch_tile_nt(k_fwd_stream<NT, P, MODE, true, false, LT>, a, NT, nblocks, lds, stream);
-    return fma ? launch_tile_nt(k_fwd_stream<NT, P, MODE, false, true, 0>, a, NT, nblocks, lds, stream)
-               : launch_tile_nt(k_fwd_stream<NT, P, MODE, false, false, 0>, a, NT, nblocks, lds, stream);
-}
-// filters of exactly 8 + 8 taps (db4, sym4, ...) on 16-byte-aligned rows take the fully unrolled tap loop
-template <int NT, int P, int MODE>
-static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (a.lh == 8 && a.lg == 8 && getenv("VW_NO_UNROLL") == nullptr)
-        return launch_fwd_stream_lt<NT, P, MODE, 8>(a, vec2, fma, nblocks, lds, stream);
-    return launch_fwd_stream_lt<NT, P, MODE, 0>(a, vec2, fma, nblocks, lds, stream);
-}
-#define VW_FWD_CASE(P, H)                                                                                    \
-    if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
-        return mode == kPeriodic ? launch_fwd_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
-                                 : launch_fwd_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-#define VW_FWD_STREAM_CASE(NT, P)                                                                            \
-    if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == NT)                                                        \
-        return mode == kPeriodic ? launch_fwd_stream_pm<NT, P, kPeriodic>(a, vec2, fma, nblocks, lds, stream) \
-                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-
-static hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
-                             hipStream_t stream) {
-    const size_t lds = cfg.lds_bytes(false);
-    VW_FWD_STREAM_CASE(256, 1)
-    VW_FWD_STREAM_CASE(256, 2)
-    VW_FWD_STREAM_CASE(256, 4)
-    VW_FWD_CASE(4, 2)
-    VW_FWD_CASE(8, 2)
-    VW_FWD_CASE(8, 4)
-    VW_FWD_CASE(8, 10)
-    return hipErrorInvalidValue;
-}
-
-#define VW_INV_CASE(P, H)                                                                                    \
-    if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
-        return mode == kPeriodic ? launch_inv_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
-                                 : launch_inv_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-static hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
-                             hipStream_t stream) {
-    const size_t lds = cfg.lds_bytes(true);
-    VW_INV_CASE(1, 1)
-    VW_INV_CASE(2, 1)
-    VW_INV_CASE(4, 1)
-    VW_INV_CASE(8, 1)
-    VW_INV_CASE(4, 2)
-    VW_INV_CASE(8, 2)
-    VW_INV_CASE(8, 4)
-    VW_INV_CASE(8, 10)
-    return hipErrorInvalidValue;
-}
-
 // Streaming forward: split each row into runs of consecutive tiles, one workgroup per run.  Long runs
 // amortise the one halo a run pays for; short runs keep enough workgroups in flight when the batch
 // is small.  VW_FWD_CHUNKS caps the run length (1 = one tile per workgroup, as the halo kernels do).
@@ -397,12 +296,6 @@ static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
 // Long-context streaming (k_fwd_sdry / k_inv_sdry): shape 1 = 512 lanes, 2048-sample tiles, histories up to 2046
 // samples per level; shape 2 = 512 lanes, 4096-sample tiles, histories up to 2558.  Returns 0 if the
 // level group does not fit either.
-struct SdryShape {
-    int nt, ppt, hb;
-    int tile() const { return ppt * 2 * nt; }
-};
-static const SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
-
 static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, int32_t* hoff, int32_t* hlen, int* ndry,
                      int* hist_cap) {
     int64_t sum = 0, hmax = 0;
@@ -428,46 +321,6 @@ static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, 
         return v;
     }
     return 0;
-}
-
-template <int NT, int P, int HB, int MODE>
-static hipError_t launch_fwd_sdry_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
-                         : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
-    return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
-               : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
-}
-static hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
-                                  hipStream_t stream) {
-    const SdryShape& sh = kSdry[shape];
-    const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8;
-    if (shape == 1)
-        return mode == kPeriodic ? launch_fwd_sdry_pm<512, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
-                                 : launch_fwd_sdry_pm<512, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-    if (shape == 2)
-        return mode == kPeriodic ? launch_fwd_sdry_pm<512, 4, 5, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
-                                 : launch_fwd_sdry_pm<512, 4, 5, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-    return hipErrorInvalidValue;
-}
-
-template <int NT, int P, int HB, int MODE>
-static hipError_t launch_inv_sdry_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
-                         : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
-    return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
-               : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
-}
-static hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
-                                  hipStream_t stream) {
-    const SdryShape& sh = kSdry[shape];
-    const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8 * 2;
-    if (shape == 1)
-        return mode == kPeriodic ? launch_inv_sdry_pm<512, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
-                                 : launch_inv_sdry_pm<512, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-    if (shape == 2)
-        return mode == kPeriodic ? launch_inv_sdry_pm<512, 4, 5, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
-                                 : launch_inv_sdry_pm<512, 4, 5, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
-    return hipErrorInvalidValue;
 }
 
 // Run length of the long-context kernels: long enough to amortise the warm-up tiles, short enough to

@@ -1180,482 +1180,4 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// generic one-level kernels (any boundary, any N / L, truncated filters):
-// one lane per output sample, operands through the cache hierarchy.  Used for
-// SYMMETRIC, for filters longer than the signal and for halos that exceed LDS.
-// ---------------------------------------------------------------------------
-
-struct LevelArgs {
-    const double* in;   // forward: V_{j-1}; inverse: R_j
-    int64_t in_stride;
-    const double* din;  // inverse only: W_j
-    int64_t din_stride;
-    double* out_lo;     // forward: V_j; inverse: R_{j-1}
-    int64_t out_lo_stride;
-    double* out_hi;     // forward: W_j (may be nullptr)
-    int64_t out_hi_stride;
-    int64_t n;
-    int64_t nrows;
-    int64_t stride;     // 2^(j-1)
-    int32_t llo, lhi;   // taps used of lo / hi (after the reference's truncation)
-    int32_t variant;    // inverse SYMMETRIC flavour, see k_level_inv
-    int32_t use_in, use_din;  // 0 = treat the operand as all zeros
-    Taps taps;
-};
-
-template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_level_fwd(const LevelArgs a) {
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    const int64_t per_row = (a.n + kThreads - 1) / kThreads * kThreads;
-    const int64_t row = gid / per_row;
-    const int64_t t = gid - row * per_row;
-    if (row >= a.nrows || t >= a.n) return;
-    const double* __restrict__ x = a.in + row * a.in_stride;
-    const int64_t n = a.n;
-    const int lmax = a.llo > a.lhi ? a.llo : a.lhi;
-    double slo = 0.0, shi = 0.0;
-    for (int l = 0; l < lmax; ++l) {
-        int64_t idx = t - static_cast<int64_t>(l) * a.stride;
-        bool ok = true;
-        if (MODE == kPeriodic) {
-            if (idx < 0) idx = (idx >= -n) ? idx + n : mod_wrap(idx, n);
-        } else if (MODE == kZeroPad) {
-            ok = idx >= 0;
-        } else {
-            idx = sym_reflect(idx, n);
-        }
-        if (ok) {
-            const double v = x[idx];
-            if (l < a.llo) slo = slo + v * a.taps.lo[l];
-            if (l < a.lhi) shi = shi + v * a.taps.hi[l];
-        }
-    }
-    if (a.out_lo != nullptr) a.out_lo[row * a.out_lo_stride + t] = slo;
-    if (a.out_hi != nullptr) a.out_hi[row * a.out_hi_stride + t] = shi;
-}
-
-// variant (SYMMETRIC only):
-//   0  MultiLevelMODWTTransform.applyScaledInverseMODWT: reflect(t - l*s), the two
-//      products added to the sum one after the other, per-filter length guards
-//   1  MODWTTransform.inverse: reflect(t - l), pair-sum, l < llo
-//   2  MODWTTransform.inverseBatchOptimized: reflect(t + l), pair-sum, l < llo
-template <int MODE>
-__global__ void __launch_bounds__(kThreads) k_level_inv(const LevelArgs a) {
-    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    const int64_t per_row = (a.n + kThreads - 1) / kThreads * kThreads;
-    const int64_t row = gid / per_row;
-    const int64_t t = gid - row * per_row;
-    if (row >= a.nrows || t >= a.n) return;
-    const double* __restrict__ ap = a.in + row * a.in_stride;
-    const double* __restrict__ dp = a.din + row * a.din_stride;
-    const int64_t n = a.n;
-    double sum = 0.0;
-    if (MODE == kSymmetric && a.variant == 0) {
-        const int lmax = a.llo > a.lhi ? a.llo : a.lhi;
-        for (int l = 0; l < lmax; ++l) {
-            const int64_t idx = sym_reflect(t - static_cast<int64_t>(l) * a.stride, n);
-            if (l < a.llo) sum = sum + a.taps.lo[l] * (a.use_in ? ap[idx] : 0.0);
-            if (l < a.lhi) sum = sum + a.taps.hi[l] * (a.use_din ? dp[idx] : 0.0);
-        }
-    } else {
-        for (int l = 0; l < a.llo; ++l) {
-            int64_t idx;
-            bool ok = true;
-            if (MODE == kPeriodic) {
-                idx = (t + static_cast<int64_t>(l) * a.stride) % n;
-            } else if (MODE == kZeroPad) {
-                idx = t + static_cast<int64_t>(l) * a.stride;
-                ok = idx < n;
-            } else if (a.variant == 1) {
-                idx = sym_reflect(t - static_cast<int64_t>(l) * a.stride, n);
-            } else {
-                idx = sym_reflect(t + static_cast<int64_t>(l) * a.stride, n);
-            }
-            if (ok) {
-                const double av = a.use_in ? ap[idx] : 0.0;
-                const double dv = a.use_din ? dp[idx] : 0.0;
-                sum = sum + (a.taps.lo[l] * av + a.taps.hi[l] * dv);
-            }
-        }
-    }
-    a.out_lo[row * a.out_lo_stride + t] = sum;
-}
-
-// ---------------------------------------------------------------------------
-// element-wise kernels
-// ---------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(kThreads) k_threshold(const double* __restrict__ in, double* __restrict__ out,
-                                                        int64_t count, double thr, int mode) {
-    int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    const int64_t step = static_cast<int64_t>(gridDim.x) * kThreads;
-    for (; i < count; i += step) out[i] = apply_thr(in[i], thr, mode);
-}
-
-__global__ void __launch_bounds__(kThreads) k_first_non_finite(const double* __restrict__ in, int64_t count,
-                                                               unsigned long long* first_bad) {
-    int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-    const int64_t step = static_cast<int64_t>(gridDim.x) * kThreads;
-    unsigned long long best = ~0ull;
-    for (; i < count; i += step)
-        if (!finite_f64(in[i]) && static_cast<unsigned long long>(i) < best) best = static_cast<unsigned long long>(i);
-    if (best != ~0ull) atomicMin(first_bad, best);
-}
-
-// ---------------------------------------------------------------------------
-// universal threshold: exact median of |d_1| per row by radix select
-// ---------------------------------------------------------------------------
-//
-// |x| of a finite double orders like its bit pattern as an unsigned integer, so
-// the k-th order statistic is found by an 8-bit-per-pass radix descent over the
-// keys.  One workgroup per row; the 256-bin histogram of a pass lives in LDS, the
-// bin that holds rank k is located with a wavefront prefix scan (DPP shuffles)
-// plus a 4-entry cross-wave fix-up.  Even N needs ranks N/2-1 and N/2 (the
-// reference averages the two middle elements of the sorted array): the second
-// one is either the same key (duplicates) or the smallest key above the first.
-
-__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned up = __shfl_up(v, d, 64);
-        if ((threadIdx.x & 63) >= d) v += up;
-    }
-    return v;
-}
-
-// Key source: either the LDS copy of the row (n <= cap) or global memory.
-struct KeySrc {
-    const unsigned long long* lds;
-    const double* glob;
-    __device__ __forceinline__ unsigned long long get(int64_t i) const {
-        if (lds != nullptr) return lds[i];
-        return static_cast<unsigned long long>(__double_as_longlong(glob[i])) & 0x7fffffffffffffffull;
-    }
-};
-
-// Returns the key of rank k (0-based) among n keys; all threads get the result.
-__device__ unsigned long long radix_select(const KeySrc& src, int64_t n, int64_t k, unsigned* hist /*256*/,
-                                           unsigned* wsum /*4*/, unsigned long long* bcast /*2*/) {
-    const int tid = threadIdx.x;
-    unsigned long long prefix = 0;
-    int64_t kk = k;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
-        __syncthreads();
-        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
-        for (int64_t i = tid; i < n; i += kThreads) {
-            const unsigned long long key = src.get(i);
-            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
-        }
-        __syncthreads();
-        // inclusive scan of the 256 bins: bin `tid` belongs to lane tid
-        const unsigned cnt = hist[tid];
-        unsigned inc = wave_inclusive_scan(cnt);
-        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        __syncthreads();
-        unsigned add = 0;
-        for (int w = 0; w < (tid >> 6); ++w) add += wsum[w];
-        inc += add;
-        const unsigned exc = inc - cnt;
-        if (cnt != 0 && static_cast<int64_t>(exc) <= kk && kk < static_cast<int64_t>(inc)) {
-            bcast[0] = prefix | (static_cast<unsigned long long>(tid) << shift);
-            bcast[1] = static_cast<unsigned long long>(kk - exc);
-        }
-        __syncthreads();
-        prefix = bcast[0];
-        kk = static_cast<int64_t>(bcast[1]);
-        __syncthreads();
-    }
-    return prefix;
-}
-
-struct MedianArgs {
-    const double* d1;      // band d_1 of row r at d1 + r*row_stride
-    int64_t row_stride;
-    int64_t n;
-    int64_t nrows;
-    double sqrt_2_ln_n;
-    double* thr_out;       // [nrows]
-    int32_t lds_cap;       // rows up to this length are copied into LDS
-};
-
-__global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianArgs a) {
-    extern __shared__ double2 vw_smem[];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned long long bcast[2];
-    __shared__ unsigned long long red[kThreads];
-    const int tid = threadIdx.x;
-    const int64_t row = blockIdx.x;
-    const int64_t n = a.n;
-    const double* __restrict__ d = a.d1 + row * a.row_stride;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(vw_smem);
-
-    KeySrc src;
-    src.glob = d;
-    src.lds = nullptr;
-    if (n <= a.lds_cap) {
-        for (int64_t i = tid; i < n; i += kThreads)
-            keys[i] = static_cast<unsigned long long>(__double_as_longlong(d[i])) & 0x7fffffffffffffffull;
-        src.lds = keys;
-        __syncthreads();
-    }
-    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
-    const unsigned long long v1 = radix_select(src, n, k1, hist, wsum, bcast);
-    double median;
-    if (n % 2 != 0) {
-        median = __longlong_as_double(static_cast<long long>(v1));
-    } else {
-        // rank k1+1: v1 again if at least k1+2 keys are <= v1, else the smallest key above v1
-        unsigned long long le = 0, above = ~0ull;
-        for (int64_t i = tid; i < n; i += kThreads) {
-            const unsigned long long key = src.get(i);
-            if (key <= v1)
-                ++le;
-            else if (key < above)
-                above = key;
-        }
-        red[tid] = le;
-        __syncthreads();
-        for (int w = kThreads / 2; w > 0; w >>= 1) {
-            if (tid < w) red[tid] += red[tid + w];
-            __syncthreads();
-        }
-        const unsigned long long le_total = red[0];
-        __syncthreads();
-        red[tid] = above;
-        __syncthreads();
-        for (int w = kThreads / 2; w > 0; w >>= 1) {
-            if (tid < w && red[tid + w] < red[tid]) red[tid] = red[tid + w];
-            __syncthreads();
-        }
-        const unsigned long long v2 = (static_cast<int64_t>(le_total) >= k1 + 2) ? v1 : red[0];
-        median = (__longlong_as_double(static_cast<long long>(v1)) +
-                  __longlong_as_double(static_cast<long long>(v2))) / 2.0;
-    }
-    if (tid == 0) {
-        const double sigma = median / 0.6745;
-        a.thr_out[row] = sigma * a.sqrt_2_ln_n;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// WaveletDenoiser threshold selection: one workgroup per (row, level)
-// ---------------------------------------------------------------------------
-//
-// UNIVERSAL and MINIMAX are closed forms of the row's sigma.  BAYES needs the mean and variance of the
-// band summed in index order (one lane adds, the others stage the band through LDS so that the adder
-// never waits for HBM).  SURE evaluates the risk of every candidate threshold |c_k| -- O(n^2) like the
-// reference -- one candidate per lane, each risk summed in index order, then the smallest risk (ties:
-// the smallest threshold, which is what scanning the sorted candidates for the first minimum yields).
-
-struct DenoiserThrArgs {
-    const double* coeffs;  // detail band j of row r at coeffs + r*row_stride + (j-1)*band_stride
-    int64_t row_stride, band_stride;
-    int64_t n;
-    int64_t nrows;
-    int32_t levels;
-    int32_t method;        // 0 UNIVERSAL, 1 SURE, 2 MINIMAX, 3 BAYES
-    int32_t level_scaled;  // 1: sigma_j = sigma / sqrt(1 << (j-1)) (multi-level form)
-    double log_n;          // Math.log(n), computed by the host
-    const double* sigma;   // [nrows] MAD estimate from the finest band
-    double* thr;           // [nrows][levels]
-};
-
-constexpr int kThrChunk = 4096;  // doubles of a band staged in LDS at a time
-
-__global__ void __launch_bounds__(kThreads) k_denoiser_thresholds(const DenoiserThrArgs a) {
-    __shared__ double stage[kThrChunk];
-    __shared__ double red_r[kThreads];
-    __shared__ double red_t[kThreads];
-    __shared__ double bc[2];
-    const int tid = threadIdx.x;
-    const int64_t row = blockIdx.x / a.levels;
-    const int level = static_cast<int>(blockIdx.x - row * a.levels) + 1;
-    const int64_t n = a.n;
-    const double* __restrict__ c = a.coeffs + row * a.row_stride + static_cast<int64_t>(level - 1) * a.band_stride;
-    double sigma = a.sigma[row];
-    if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (level - 1)));
-    double* out = a.thr + row * a.levels + (level - 1);
-    const double universal = sigma * sqrt(2.0 * a.log_n);
-
-    if (a.method == 0) {
-        if (tid == 0) *out = universal;
-        return;
-    }
-    if (a.method == 2) {
-        if (tid == 0) {
-            double t;
-            if (n <= 32)
-                t = 0;
-            else if (n <= 64)
-                t = sigma * 0.3936 + 0.1829 * sigma * a.log_n;
-            else
-                t = sigma * (0.4745 + 0.1148 * a.log_n);
-            *out = t;
-        }
-        return;
-    }
-    if (a.method == 3) {
-        // pass 0: mean; pass 1: variance around it -- each a running sum in index order
-        double mean = 0.0, variance = 0.0;
-        for (int pass = 0; pass < 2; ++pass) {
-            double acc = 0.0;
-            for (int64_t base = 0; base < n; base += kThrChunk) {
-                const int cnt = static_cast<int>((n - base) < kThrChunk ? (n - base) : kThrChunk);
-                for (int i = tid; i < cnt; i += kThreads) stage[i] = c[base + i];
-                __syncthreads();
-                if (tid == 0) {
-                    if (pass == 0) {
-                        for (int i = 0; i < cnt; ++i) acc += stage[i];
-                    } else {
-                        for (int i = 0; i < cnt; ++i) {
-                            const double diff = stage[i] - mean;
-                            acc += diff * diff;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            if (tid == 0) {
-                if (pass == 0) {
-                    mean = acc / static_cast<double>(n);
-                    bc[0] = mean;
-                } else {
-                    variance = acc / static_cast<double>(n);
-                }
-            }
-            __syncthreads();
-            mean = bc[0];
-        }
-        if (tid == 0) {
-            const double sigma2 = sigma * sigma;
-            const double d = variance - sigma2;
-            const double sx2 = d > 0.0 ? d : 0.0;
-            const double sx = sqrt(sx2 + 1e-10);
-            *out = sigma2 / sx;
-        }
-        return;
-    }
-    // SURE
-    const double sigma2 = sigma * sigma;
-    double best_risk = __builtin_inf(), best_t = 0.0;
-    const bool in_lds = n <= kThrChunk;
-    if (in_lds) {
-        for (int i = tid; i < n; i += kThreads) stage[i] = c[i];
-        __syncthreads();
-    }
-    for (int64_t k = tid; k < n; k += kThreads) {
-        const double t = fabs(in_lds ? stage[k] : c[k]);
-        double risk = -static_cast<double>(n) * sigma2;
-        for (int64_t i = 0; i < n; ++i) {
-            const double v = in_lds ? stage[i] : c[i];
-            const double av = fabs(v);
-            if (av <= t) {
-                risk += v * v;
-            } else {
-                risk += sigma2 + (av - t) * (av - t);
-            }
-        }
-        risk = risk / static_cast<double>(n);
-        if (risk < best_risk || (risk == best_risk && t < best_t)) {
-            best_risk = risk;
-            best_t = t;
-        }
-    }
-    red_r[tid] = best_risk;
-    red_t[tid] = best_t;
-    __syncthreads();
-    for (int w = kThreads / 2; w > 0; w >>= 1) {
-        if (tid < w) {
-            const double r2 = red_r[tid + w], t2 = red_t[tid + w];
-            if (r2 < red_r[tid] || (r2 == red_r[tid] && t2 < red_t[tid])) {
-                red_r[tid] = r2;
-                red_t[tid] = t2;
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        double best = red_t[0];
-        // the reference starts from minRisk = +inf, bestThreshold = 0: a band whose risks are all NaN or
-        // +inf keeps 0
-        if (!(red_r[0] < __builtin_inf())) best = 0.0;
-        if (best > universal) best = universal;
-        *out = best;
-    }
-}
-
-
-// BAYES thresholds, 64 bands per single-wave workgroup.  The mean and the variance must be running sums
-// in index order (that is what the Java loops round to), so a band is one dependent chain of adds; the
-// parallelism is across bands: every lane owns one (row, level) band and adds its elements in order,
-// while the wave loads the 64 bands' next 64 elements with coalesced 512-byte reads and transposes
-// them through LDS (row stride 65 doubles: conflict-free both ways).
-__global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) {
-    __shared__ double tile[64 * 65];
-    const int lane = threadIdx.x;
-    const int64_t nbands = a.nrows * a.levels;
-    const int64_t band0 = static_cast<int64_t>(blockIdx.x) * 64;
-    const int64_t n = a.n;
-    const int64_t mine = band0 + lane;
-    const bool have = mine < nbands;
-    const int64_t my_row = have ? mine / a.levels : 0;
-    const int my_level = have ? static_cast<int>(mine - my_row * a.levels) + 1 : 1;
-    const unsigned long long my_ptr = reinterpret_cast<unsigned long long>(
-        a.coeffs + my_row * a.row_stride + static_cast<int64_t>(my_level - 1) * a.band_stride);
-    const int nq = static_cast<int>((nbands - band0) < 64 ? (nbands - band0) : 64);
-    double mean = 0.0, variance = 0.0;
-    for (int pass = 0; pass < 2; ++pass) {
-        double acc = 0.0;
-        for (int64_t base = 0; base < n; base += 64) {
-            const int cnt = static_cast<int>((n - base) < 64 ? (n - base) : 64);
-            // wave-uniform loop over the 64 bands: lane = element index within the chunk; band q's base
-            // address lives in lane q
-            // 16 loads in flight at a time, then 16 LDS writes
-#pragma unroll
-            for (int q0 = 0; q0 < 64; q0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int q = q0 + u;
-                    const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(my_ptr & 0xffffffffu), q);
-                    const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(my_ptr >> 32), q);
-                    const double* __restrict__ c =
-                        reinterpret_cast<const double*>((static_cast<unsigned long long>(hi) << 32) | lo);
-                    v[u] = (q < nq && lane < cnt) ? c[base + lane] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) tile[(q0 + u) * 65 + lane] = v[u];
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // one wave: no barrier needed
-            if (have) {
-                if (pass == 0) {
-                    for (int i = 0; i < cnt; ++i) acc += tile[lane * 65 + i];
-                } else {
-                    for (int i = 0; i < cnt; ++i) {
-                        const double diff = tile[lane * 65 + i] - mean;
-                        acc += diff * diff;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (pass == 0)
-            mean = acc / static_cast<double>(n);
-        else
-            variance = acc / static_cast<double>(n);
-    }
-    if (have) {
-        double sigma = a.sigma[my_row];
-        if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (my_level - 1)));
-        const double sigma2 = sigma * sigma;
-        const double d = variance - sigma2;
-        const double sx2 = d > 0.0 ? d : 0.0;
-        const double sx = sqrt(sx2 + 1e-10);
-        a.thr[my_row * a.levels + (my_level - 1)] = sigma2 / sx;
-    }
-}
-
 }  // namespace vw

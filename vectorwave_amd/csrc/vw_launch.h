@@ -1,0 +1,49 @@
+// vw_launch.h -- tile shapes and the launchers of the tiled kernels.  The kernel templates are
+// instantiated in vw_launch_fwd.hip and vw_launch_inv.hip (separate translation units so that they
+// compile in parallel); the planner in vw_capi.hip only picks shapes and fills argument blocks.
+#pragma once
+#include "vw_kernels.hip.h"
+
+namespace vw {
+
+struct TileCfg {
+    int ppt, hpt, nt;  // tile = ppt chunks of 2*nt samples, halo = hpt * 512 samples, nt lanes per workgroup
+    int tile() const { return ppt * 2 * nt; }
+    // forward shapes with a one-chunk halo run the tile-streaming kernel (one buffer + level histories);
+    // everything else runs the one-tile-per-workgroup kernels (two buffers)
+    size_t lds_bytes(bool inverse) const {
+        const size_t m = static_cast<size_t>(tile()) + static_cast<size_t>(hpt) * kChunk;
+        if (!inverse && hpt == 1) return (m + kChunk) * 8;
+        return 2 * m * 8;
+    }
+};
+
+struct SdryShape {
+    int nt, ppt, hb;
+    int tile() const { return ppt * 2 * nt; }
+};
+constexpr SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
+
+
+hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+
+// shared by the launcher units
+template <typename K, typename A>
+static hipError_t launch_tile_nt(K kernel, const A& args, int nt, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(nblocks)), dim3(nt), lds, stream, args);
+    return hipGetLastError();
+}
+template <typename K, typename A>
+static hipError_t launch_tile(K kernel, const A& args, int64_t nblocks, size_t lds, hipStream_t stream) {
+    return launch_tile_nt(kernel, args, kThreads, nblocks, lds, stream);
+}
+
+}  // namespace vw
