@@ -271,6 +271,27 @@ int32_t vw_denoiser_thresholds_batch_dev(vw_ctx *ctx, const double *coeffs_dev, 
                                          double log_n, double *thresholds_dev, double *sigma_scratch_dev,
                                          void *stream);
 
+/* ---- structure-of-arrays batch ---------------------------------------------- */
+
+/* BatchSIMDMODWT.batchMODWTSoA(soaSignals, soaApprox, soaDetail, wavelet, batchSize, signalLength)
+ * (modwt/BatchSIMDMODWT.java:64-81): single-level PERIODIC MODWT of `batch` signals stored sample-major,
+ * soa[t * batch + b].  The reference's three code paths round differently and are all kept:
+ * is_haar != 0 -> the Haar path with the literal constants 0.5 (:86-139); lh == 4 -> the four-tap path
+ * (:144-211); otherwise the general path (:216-274).  Filters unscaled, as everywhere in this ABI. */
+int32_t vw_batch_modwt_soa(vw_ctx *ctx, const double *soa_signals, int64_t batch, int64_t n,
+                           const double *h, int32_t lh, const double *g, int32_t lg, int32_t is_haar,
+                           double *soa_approx, double *soa_detail);
+int32_t vw_batch_modwt_soa_dev(vw_ctx *ctx, const double *soa_signals_dev, int64_t batch, int64_t n,
+                               const double *h, int32_t lh, const double *g, int32_t lg,
+                               int32_t is_haar, double *soa_approx_dev, double *soa_detail_dev,
+                               void *stream);
+
+/* BatchSIMDMODWT.convertToSoA / convertFromSoA (modwt/BatchSIMDMODWT.java:282-308): out[c][r] =
+ * in[r][c] for a rows x cols matrix (to SoA: rows = batch, cols = N; back: rows = N, cols = batch). */
+int32_t vw_transpose(vw_ctx *ctx, const double *in, int64_t rows, int64_t cols, double *out);
+int32_t vw_transpose_dev(vw_ctx *ctx, const double *in_dev, int64_t rows, int64_t cols, double *out_dev,
+                         void *stream);
+
 /* Per-signal universal threshold of an existing decomposition
  * (VectorWaveSwtAdapter.applyUniversalThreshold's threshold value,
  * swt/VectorWaveSwtAdapter.java:255-264): thresholds[b] from band d_1 of

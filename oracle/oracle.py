@@ -144,6 +144,47 @@ def swt_denoise_batch(x, wavelet, levels, threshold=-1.0, soft=True, boundary=PE
     return int(st), out
 
 
+def convert_to_soa(signals):
+    """BatchSIMDMODWT.convertToSoA: [B][N] -> flat [N*B] with soa[t*B + b]."""
+    x = _f64(signals)
+    b, n = x.shape
+    out = np.empty(b * n)
+    lib().vwo_convert_to_soa(_p(x), C.c_int64(b), C.c_int64(n), _p(out))
+    return out
+
+
+def convert_from_soa(soa, batch, n):
+    s = _f64(soa)
+    out = np.empty((batch, n))
+    lib().vwo_convert_from_soa(_p(s), C.c_int64(batch), C.c_int64(n), _p(out))
+    return out
+
+
+def batch_modwt_soa(soa, wavelet, batch, n):
+    """BatchSIMDMODWT.batchMODWTSoA: returns (soaApprox, soaDetail)."""
+    s = _f64(soa)
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    a, d = np.empty(batch * n), np.empty(batch * n)
+    lib().vwo_batch_modwt_soa(_p(s), _p(a), _p(d), _p(h), _p(g), C.c_int(h.size), C.c_int(1 if wavelet.name == "haar" else 0),
+                              C.c_int64(batch), C.c_int64(n))
+    return a, d
+
+
+def parallel_max_levels(n, filter_len):
+    return int(lib().vwo_parallel_max_levels(C.c_int64(n), C.c_int(filter_len)))
+
+
+def parallel_decompose(x, wavelet, levels, boundary=PERIODIC):
+    """ParallelMultiLevelMODWT.decompose for one signal: (status, coeffs [J+1][N])."""
+    x = _f64(x)
+    n = x.size
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    out = np.empty((max(levels, 0) + 1, n))
+    st = lib().vwo_parallel_decompose(_p(x), C.c_int64(n), C.c_int(levels), _p(h), C.c_int(h.size), _p(g), C.c_int(g.size),
+                                      C.c_int(boundary), _p(out))
+    return int(st), out
+
+
 UNIVERSAL, SURE, MINIMAX, BAYES, FIXED = 0, 1, 2, 3, 4
 
 

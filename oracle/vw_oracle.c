@@ -597,6 +597,101 @@ int vwo_wavelet_denoise_batch(const double *x, int64_t b, int64_t n, int levels,
 }
 
 /* ------------------------------------------------------------------------ */
+/* modwt/BatchSIMDMODWT.java (structure-of-arrays batch) and ParallelMultiLevelMODWT.java */
+/* ------------------------------------------------------------------------ */
+
+/* modwt/BatchSIMDMODWT.java:282-291: soa[t * batch + b] = signals[b][t] */
+void vwo_convert_to_soa(const double *aos, int64_t batch, int64_t n, double *soa) {
+    for (int64_t t = 0; t < n; t++)
+        for (int64_t b = 0; b < batch; b++) soa[t * batch + b] = aos[b * n + t];
+}
+
+/* modwt/BatchSIMDMODWT.java:299-308 */
+void vwo_convert_from_soa(const double *soa, int64_t batch, int64_t n, double *aos) {
+    for (int64_t t = 0; t < n; t++)
+        for (int64_t b = 0; b < batch; b++) aos[b * n + t] = soa[t * batch + b];
+}
+
+/* modwt/BatchSIMDMODWT.java:64-81 (dispatch): Haar -> :86-139 (constants 0.5, no running sum),
+ * four taps -> :144-211 (taps * 1/sqrt(2), products chained without a zero start),
+ * else -> :216-274 (running sums from zero).  Lane-wise vector arithmetic = the same scalar
+ * operations per (t, b).  Source index (t - l + N) % N.  `hi` must hold at least flen taps (the
+ * reference indexes highPass[l] for l < lowPass.length and throws when it is shorter). */
+void vwo_batch_modwt_soa(const double *soa, double *soa_approx, double *soa_detail, const double *lo,
+                         const double *hi, int flen, int is_haar, int64_t batch, int64_t n) {
+    const double scale = 1.0 / sqrt(2.0);
+    if (is_haar) {
+        const double h0 = 0.5, h1 = 0.5, g0 = 0.5, g1 = -0.5;
+        for (int64_t t = 0; t < n; t++) {
+            int64_t tm1 = (t - 1 + n) % n;
+            for (int64_t b = 0; b < batch; b++) {
+                double s0 = soa[t * batch + b], s1 = soa[tm1 * batch + b];
+                soa_approx[t * batch + b] = s0 * h0 + s1 * h1;
+                soa_detail[t * batch + b] = s0 * g0 + s1 * g1;
+            }
+        }
+    } else if (flen == 4) {
+        double h[4], g[4];
+        for (int i = 0; i < 4; i++) {
+            h[i] = lo[i] * scale;
+            g[i] = hi[i] * scale;
+        }
+        for (int64_t t = 0; t < n; t++) {
+            int64_t i1 = (t - 1 + n) % n, i2 = (t - 2 + n) % n, i3 = (t - 3 + n) % n;
+            for (int64_t b = 0; b < batch; b++) {
+                double s0 = soa[t * batch + b], s1 = soa[i1 * batch + b], s2 = soa[i2 * batch + b],
+                       s3 = soa[i3 * batch + b];
+                soa_approx[t * batch + b] = ((s0 * h[0] + s1 * h[1]) + s2 * h[2]) + s3 * h[3];
+                soa_detail[t * batch + b] = ((s0 * g[0] + s1 * g[1]) + s2 * g[2]) + s3 * g[3];
+            }
+        }
+    } else {
+        double *h = scaled_copy(lo, flen), *g = scaled_copy(hi, flen);
+        for (int64_t t = 0; t < n; t++) {
+            for (int64_t b = 0; b < batch; b++) {
+                double sa = 0.0, sd = 0.0;
+                for (int l = 0; l < flen; l++) {
+                    int64_t src = (t - l + n) % n;
+                    double v = soa[src * batch + b];
+                    sa = sa + v * h[l];
+                    sd = sd + v * g[l];
+                }
+                soa_approx[t * batch + b] = sa;
+                soa_detail[t * batch + b] = sd;
+            }
+        }
+        free(h);
+        free(g);
+    }
+}
+
+/* modwt/ParallelMultiLevelMODWT.java:218-248 (calculateMaxLevels; note the extra
+ * signalLength <= filterLength rule) */
+int vwo_parallel_max_levels(int64_t n, int filter_len) {
+    if (n <= filter_len) return 0;
+    int max_level = 1;
+    int64_t lm1 = filter_len - 1;
+    while (max_level < 10) {
+        if (max_level - 1 >= 31) break;
+        int64_t scaled = lm1 * ((int64_t)1 << (max_level - 1)) + 1;
+        if (scaled > n) break;
+        max_level++;
+    }
+    return max_level - 1;
+}
+
+/* modwt/ParallelMultiLevelMODWT.java:59-152: levels in [1, max]; PERIODIC -> circular convolution with
+ * the zero-stuffed, 1/sqrt(2)-scaled filters (:172-208), every other mode -> zero padding (:100-131).
+ * Within its level limit no filter is longer than the signal, so the cascade equals
+ * vwo_multilevel_decompose.  Returns 104 (CFG_INVALID_DECOMPOSITION_LEVEL-like) for bad levels. */
+int vwo_parallel_decompose(const double *x, int64_t n, int levels, const double *h, int lh, const double *g,
+                           int lg, int boundary, double *coeffs) {
+    int maxl = vwo_parallel_max_levels(n, lh);
+    if (levels < 1 || levels > maxl) return 104;
+    return vwo_multilevel_decompose(x, n, levels, h, lh, g, lg, boundary == 0 ? 0 : 1, coeffs);
+}
+
+/* ------------------------------------------------------------------------ */
 /* batch drivers (row loops, OpenMP over signals) used by tests + cpu_baseline */
 /* ------------------------------------------------------------------------ */
 

@@ -108,6 +108,31 @@ def main():
                 print(name, res[name], flush=True)
             del x, y
             torch.cuda.empty_cache()
+    # BatchSIMDMODWT.batchMODWTSoA: single-level transform of a sample-major batch (24 B/sample)
+    if not args.only or "N3" in args.only:
+        from vectorwave_amd.wavelets import get_wavelet
+        rows, n = 65536, 4096
+        soa = torch.randn((n, rows), dtype=torch.float64, device="cuda")
+        a = torch.empty_like(soa)
+        d = torch.empty_like(soa)
+        sp = C.c_void_p(stream.cuda_stream)
+        dp = C.POINTER(C.c_double)
+        for wn in ("haar", "db2", "db4"):
+            w = get_wavelet(wn)
+            import numpy as np
+            h = np.ascontiguousarray(w.dec_lo, dtype=np.float64)
+            g = np.ascontiguousarray(w.dec_hi, dtype=np.float64)
+
+            def run():
+                st = ctx.lib.vw_batch_modwt_soa_dev(ctx.handle, C.c_void_p(soa.data_ptr()), rows, n, h.ctypes.data_as(dp), h.size,
+                                                    g.ctypes.data_as(dp), g.size, 1 if wn == "haar" else 0,
+                                                    C.c_void_p(a.data_ptr()), C.c_void_p(d.data_ptr()), sp)
+                assert st == 0, ctx.last_error()
+            ms = timed(run)
+            name = "N3 %s batchMODWTSoA %dx%d" % (wn, rows, n)
+            res[name] = {"forward_ms": round(ms, 4), "Gsamples_per_s": round(rows * n / (ms * 1e-3) / 1e9, 3),
+                         "algorithmic_GBps_24B_per_sample": round(24.0 * rows * n / (ms * 1e-3) / 1e9, 1)}
+            print(name, res[name], flush=True)
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)
 

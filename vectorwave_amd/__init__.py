@@ -4,8 +4,8 @@ Host mirror of the reference's MODWTTransform / MultiLevelMODWTTransform /
 VectorWaveSwtAdapter API over libvwgpu.so (hand-written gfx950 HIP kernels
 behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
-from .api import (BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult, MODWTTransform,
-                  MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult,
+from .api import (BatchSIMDMODWT, BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult, MODWTTransform,
+                  MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult, ParallelMultiLevelMODWT,
                   ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
                   WaveletTransformException)
 from .wavelets import Wavelet, available_wavelets, get_wavelet
@@ -14,5 +14,5 @@ __all__ = [
     "BoundaryMode", "InvalidArgumentException", "InvalidSignalException", "MODWTResult", "MODWTTransform",
     "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
-    "WaveletDenoiser", "ThresholdMethod", "ThresholdType",
+    "WaveletDenoiser", "ThresholdMethod", "ThresholdType", "BatchSIMDMODWT", "ParallelMultiLevelMODWT",
 ]

@@ -84,6 +84,11 @@ SIGNATURES = {
                                                  C.c_double, _vp]),
     "vw_denoiser_thresholds_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                                      C.c_double, _vp, _vp, _vp]),
+    "vw_batch_modwt_soa": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _vp, _vp]),
+    "vw_batch_modwt_soa_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _vp, _vp,
+                                           _vp]),
+    "vw_transpose": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
+    "vw_transpose_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),
     "vw_swt_universal_threshold_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp,
                                                          _vp]),

@@ -798,3 +798,88 @@ class WaveletDenoiser:
 
     def denoiseMultiLevelBatch(self, signals, levels, method, type=ThresholdType.SOFT):
         return self.denoise_block(np.ascontiguousarray(np.asarray(signals, dtype=np.float64)), int(levels), method, type)
+
+
+# ---------------------------------------------------------------------------
+# modwt/BatchSIMDMODWT.java and modwt/ParallelMultiLevelMODWT.java
+# ---------------------------------------------------------------------------
+
+class BatchSIMDMODWT:
+    """Structure-of-arrays batch surface (modwt/BatchSIMDMODWT.java): signals stored sample-major,
+    soa[t * batchSize + b].  Static methods, like the reference."""
+
+    @staticmethod
+    def batchMODWTSoA(soaSignals, soaApprox, soaDetail, wavelet, batchSize, signalLength, ctx: Optional[N.Context] = None):
+        """:64-81: single-level PERIODIC MODWT of the whole batch; fills soaApprox / soaDetail in place."""
+        ctx = ctx or N.default_context()
+        w = _as_wavelet(wavelet)
+        x = _require_signal(soaSignals, "soaSignals")
+        if soaApprox is None or soaDetail is None:
+            raise TypeError("output arrays cannot be null")
+        cnt = int(batchSize) * int(signalLength)
+        if x.size < cnt or soaApprox.size < cnt or soaDetail.size < cnt:
+            raise IndexError("SoA arrays shorter than batchSize * signalLength")
+        h, g = _taps(w.dec_lo), _taps(w.dec_hi)
+        a = np.empty(cnt)
+        d = np.empty(cnt)
+        st = ctx.lib.vw_batch_modwt_soa(ctx.handle, _vp(x), int(batchSize), int(signalLength), _dp(h), h.size, _dp(g),
+                                        g.size, 1 if w.name == "haar" else 0, _vp(a), _vp(d))
+        _raise_for_status(ctx, st)
+        soaApprox[:cnt] = a
+        soaDetail[:cnt] = d
+
+    @staticmethod
+    def convertToSoA(signals, soaOutput, ctx: Optional[N.Context] = None):
+        """:282-291: soaOutput[t * batchSize + b] = signals[b][t]"""
+        ctx = ctx or N.default_context()
+        x = np.ascontiguousarray(np.asarray(signals, dtype=np.float64))
+        b, n = x.shape
+        out = np.empty(b * n)
+        _raise_for_status(ctx, ctx.lib.vw_transpose(ctx.handle, _vp(x), b, n, _vp(out)))
+        soaOutput[: b * n] = out
+
+    @staticmethod
+    def convertFromSoA(soaData, output, ctx: Optional[N.Context] = None):
+        """:299-308: output[b][t] = soaData[t * batchSize + b]"""
+        ctx = ctx or N.default_context()
+        b, n = len(output), len(output[0])
+        s = np.ascontiguousarray(np.asarray(soaData, dtype=np.float64)[: b * n])
+        out = np.empty((b, n))
+        _raise_for_status(ctx, ctx.lib.vw_transpose(ctx.handle, _vp(s), n, b, _vp(out)))
+        for i in range(b):
+            output[i][:] = out[i]
+
+
+class ParallelMultiLevelMODWT:
+    """modwt/ParallelMultiLevelMODWT.java: the same cascade as MultiLevelMODWTTransform.decompose with its own
+    level limit (:218-248) and with every non-PERIODIC mode treated as zero padding (:100-131).  The
+    executor of the reference has no counterpart: the levels of one signal run fused in one kernel."""
+
+    def __init__(self, executor=None, ctx: Optional[N.Context] = None):
+        self._ctx = ctx
+
+    @staticmethod
+    def _max_levels(n, filter_len):
+        if n <= filter_len:
+            return 0
+        level = 1
+        while level < 10 and (filter_len - 1) * (1 << (level - 1)) + 1 <= n:
+            level += 1
+        return level - 1
+
+    def decompose(self, signal, wavelet, mode, levels) -> MultiLevelMODWTResult:
+        x = _require_signal(signal)
+        ctx = self._ctx or N.default_context()
+        # :62-66: finiteness first, then emptiness
+        bad = C.c_int64(-1)
+        if x.size:
+            _raise_for_status(ctx, ctx.lib.vw_first_non_finite(ctx.handle, _vp(x), x.size, C.byref(bad)))
+        if x.size == 0:
+            raise InvalidSignalException("Signal cannot be empty", "VAL_006")
+        w = _as_wavelet(wavelet)
+        maxl = self._max_levels(x.size, len(w.dec_lo))
+        if levels < 1 or levels > maxl:
+            raise InvalidArgumentException("Invalid number of levels: %d. Must be between 1 and %d" % (levels, maxl), "CFG_004")
+        eff = BoundaryMode.PERIODIC if BoundaryMode(mode) == BoundaryMode.PERIODIC else BoundaryMode.ZERO_PADDING
+        t = MultiLevelMODWTTransform(w, eff, ctx)
+        return MultiLevelMODWTResult(t.decompose_block(x.reshape(1, -1), int(levels), check_finite=False)[0])

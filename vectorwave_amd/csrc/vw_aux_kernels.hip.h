@@ -486,4 +486,75 @@ __global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// structure-of-arrays batch (modwt/BatchSIMDMODWT.java): sample-major storage, soa[t * B + b]
+// ---------------------------------------------------------------------------
+//
+// One lane per (t, b), lanes along b: every tap reads a contiguous run of the batch.  The three
+// arithmetic flavours of the reference are kept apart because they round differently: Haar with the
+// literal constants 0.5 and no running sum, four-tap filters as a chain of products without a zero
+// start, everything else as running sums from +0.0.
+
+struct SoaArgs {
+    const double* in;   // [N][B]
+    double* approx;     // [N][B]
+    double* detail;     // [N][B]
+    int64_t batch, n;
+    int32_t flen;
+    int32_t flavour;    // 0 general, 1 Haar constants, 2 four taps
+    Taps taps;          // scaled by 1/sqrt(2) (unused for flavour 1)
+};
+
+__global__ void __launch_bounds__(kThreads) k_soa_modwt(const SoaArgs a) {
+    const int64_t gid = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (gid >= a.n * a.batch) return;
+    const int64_t t = gid / a.batch;
+    const int64_t b = gid - t * a.batch;
+    const int64_t n = a.n, B = a.batch;
+    const double* __restrict__ x = a.in;
+    double va, vd;
+    if (a.flavour == 1) {
+        const double s0 = x[t * B + b], s1 = x[mod_wrap(t - 1, n) * B + b];
+        va = s0 * 0.5 + s1 * 0.5;
+        vd = s0 * 0.5 + s1 * -0.5;
+    } else if (a.flavour == 2) {
+        const double s0 = x[t * B + b], s1 = x[mod_wrap(t - 1, n) * B + b], s2 = x[mod_wrap(t - 2, n) * B + b],
+                     s3 = x[mod_wrap(t - 3, n) * B + b];
+        va = ((s0 * a.taps.lo[0] + s1 * a.taps.lo[1]) + s2 * a.taps.lo[2]) + s3 * a.taps.lo[3];
+        vd = ((s0 * a.taps.hi[0] + s1 * a.taps.hi[1]) + s2 * a.taps.hi[2]) + s3 * a.taps.hi[3];
+    } else {
+        double sa = 0.0, sd = 0.0;
+        int64_t src = t;
+        for (int l = 0; l < a.flen; ++l) {
+            const double v = x[src * B + b];
+            sa = sa + v * a.taps.lo[l];
+            sd = sd + v * a.taps.hi[l];
+            src = src - 1;
+            if (src < 0) src = mod_wrap(src, n);
+        }
+        va = sa;
+        vd = sd;
+    }
+    a.approx[gid] = va;
+    a.detail[gid] = vd;
+}
+
+// out[c][r] = in[r][c]; 32 x 32 tiles through LDS (row stride 33: conflict-free both ways)
+__global__ void __launch_bounds__(kThreads) k_transpose(const double* __restrict__ in, double* __restrict__ out,
+                                                        int64_t rows, int64_t cols) {
+    __shared__ double tile[32][33];
+    const int64_t tiles_c = (cols + 31) / 32;
+    const int64_t tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ly; k < 32; k += 8) {
+        const int64_t r = tr * 32 + k, c = tc * 32 + lx;
+        if (r < rows && c < cols) tile[k][lx] = in[r * cols + c];
+    }
+    __syncthreads();
+    for (int k = ly; k < 32; k += 8) {
+        const int64_t c = tc * 32 + k, r = tr * 32 + lx;
+        if (r < rows && c < cols) out[c * rows + r] = tile[lx][k];
+    }
+}
+
 }  // namespace vw

@@ -1412,6 +1412,104 @@ extern "C" int32_t vw_wavelet_denoise_batch(vw_ctx* ctx, const double* x, int64_
 }
 
 // ---------------------------------------------------------------------------
+// structure-of-arrays batch + layout conversion
+// ---------------------------------------------------------------------------
+
+extern "C" int32_t vw_transpose_dev(vw_ctx* ctx, const double* in_dev, int64_t rows, int64_t cols, double* out_dev, void* stream) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (rows < 0 || cols < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (rows == 0 || cols == 0) return VW_OK;
+    if (in_dev == nullptr || out_dev == nullptr) return set_err(ctx, VW_E_NULL, "array cannot be null");
+    const int64_t nblocks = ((rows + 31) / 32) * ((cols + 31) / 32);
+    if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_transpose, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), in_dev,
+                       out_dev, rows, cols);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_transpose(vw_ctx* ctx, const double* in, int64_t rows, int64_t cols, double* out) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (rows < 0 || cols < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (rows == 0 || cols == 0) return VW_OK;
+    if (in == nullptr || out == nullptr) return set_err(ctx, VW_E_NULL, "array cannot be null");
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(rows) * cols * 8;
+    int rc = ensure(ctx, ctx->stage_in, bytes);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, bytes);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(ctx->stage_in.p, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_transpose_dev(ctx, static_cast<const double*>(ctx->stage_in.p), rows, cols, static_cast<double*>(ctx->stage_out.p), ctx->stream);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(out, ctx->stage_out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+static int soa_checks(vw_ctx* ctx, const void* in, const void* a, const void* d, int64_t batch, int64_t n, const double* h, int lh,
+                      const double* g, int lg) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (h == nullptr || g == nullptr) return set_err(ctx, VW_E_NULL, "filter cannot be null");
+    if (batch < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (lh < 1 || lh > kMaxTaps) return set_err(ctx, VW_E_LENGTH_MISMATCH, "filter length %d outside [1, %d]", lh, kMaxTaps);
+    // the reference loops l < lowPass.length over both filters
+    if (lg < lh) return set_err(ctx, VW_E_LENGTH_MISMATCH, "high-pass filter (%d taps) shorter than low-pass (%d)", lg, lh);
+    if (batch > 0 && n > 0 && (in == nullptr || a == nullptr || d == nullptr)) return set_err(ctx, VW_E_NULL, "array cannot be null");
+    if (batch > 0 && n > 0 && batch > INT64_MAX / n / 8) return set_err(ctx, VW_E_TOO_LARGE, "batch too large");
+    return VW_OK;
+}
+
+extern "C" int32_t vw_batch_modwt_soa_dev(vw_ctx* ctx, const double* soa_signals_dev, int64_t batch, int64_t n, const double* h,
+                                          int32_t lh, const double* g, int32_t lg, int32_t is_haar, double* soa_approx_dev,
+                                          double* soa_detail_dev, void* stream) {
+    int rc = soa_checks(ctx, soa_signals_dev, soa_approx_dev, soa_detail_dev, batch, n, h, lh, g, lg);
+    if (rc != VW_OK) return rc;
+    if (batch == 0 || n == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    SoaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = soa_signals_dev;
+    a.approx = soa_approx_dev;
+    a.detail = soa_detail_dev;
+    a.batch = batch;
+    a.n = n;
+    a.flen = lh;
+    a.flavour = is_haar ? 1 : (lh == 4 ? 2 : 0);
+    scale_taps(h, lh, a.taps.lo);
+    scale_taps(g, lh, a.taps.hi);
+    const int64_t nblocks = (batch * n + kThreads - 1) / kThreads;
+    if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    hipLaunchKernelGGL(k_soa_modwt, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_batch_modwt_soa(vw_ctx* ctx, const double* soa_signals, int64_t batch, int64_t n, const double* h, int32_t lh,
+                                      const double* g, int32_t lg, int32_t is_haar, double* soa_approx, double* soa_detail) {
+    int rc = soa_checks(ctx, soa_signals, soa_approx, soa_detail, batch, n, h, lh, g, lg);
+    if (rc != VW_OK) return rc;
+    if (batch == 0 || n == 0) return VW_OK;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(batch) * n * 8;
+    rc = ensure(ctx, ctx->stage_in, bytes);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, 2 * bytes);
+    if (rc != VW_OK) return rc;
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* da = static_cast<double*>(ctx->stage_out.p);
+    double* dd = da + static_cast<size_t>(batch) * n;
+    VW_HIP(ctx, hipMemcpyAsync(dx, soa_signals, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_batch_modwt_soa_dev(ctx, dx, batch, n, h, lh, g, lg, is_haar, da, dd, ctx->stream);
+    if (rc != VW_OK) return rc;
+    VW_HIP(ctx, hipMemcpyAsync(soa_approx, da, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipMemcpyAsync(soa_detail, dd, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
 // raw convolution + validation
 // ---------------------------------------------------------------------------
 
