@@ -271,6 +271,56 @@ int32_t vw_denoiser_thresholds_batch_dev(vw_ctx *ctx, const double *coeffs_dev, 
                                          double log_n, double *thresholds_dev, double *sigma_scratch_dev,
                                          void *stream);
 
+/* ---- streaming denoiser ---------------------------------------------------- */
+
+/* MODWTStreamingDenoiser.NoiseEstimation (modwt/streaming/MODWTStreamingDenoiser.java:58-65). */
+typedef enum vw_noise_estimation {
+    VW_NOISE_MAD = 0,  /* median(|v - median(v)|) / 0.6745 over the noise window (:195, :211-241) */
+    VW_NOISE_STD = 1,  /* sample standard deviation of the noise window         (:196, :249-268) */
+    VW_NOISE_FIXED = 2 /* no window, no estimate                                (:102, :197-199) */
+} vw_noise_estimation;
+
+/* State of `streams` parallel MODWTStreamingDenoiser instances that are fed blocks of equal length in
+ * lock step (:50-54): the |detail| ring noiseWindow[window_size] and estimatedNoiseLevel per stream in
+ * device memory, the common ring position noiseWindowIndex and samplesProcessed on the host.  Created
+ * zeroed, as the Java constructor leaves them (:67-83). */
+typedef struct vw_stream_state vw_stream_state;
+int32_t vw_stream_state_create(vw_ctx *ctx, int64_t streams, int64_t window_size, vw_stream_state **out);
+int32_t vw_stream_state_destroy(vw_ctx *ctx, vw_stream_state *state);
+/* getEstimatedNoiseLevel() of every stream (:332-334): levels[streams], host memory. */
+int32_t vw_stream_state_noise_levels(vw_ctx *ctx, vw_stream_state *state, double *levels);
+/* Copy of the rings, window[streams][window_size] (host memory), and the ring position (may be NULL). */
+int32_t vw_stream_state_window(vw_ctx *ctx, vw_stream_state *state, double *window, int64_t *window_index);
+/* getSamplesProcessed() of each stream (:341-343). */
+int64_t vw_stream_state_samples_processed(const vw_stream_state *state);
+
+/* MODWTStreamingDenoiser.denoise(samples) (:93-127) for one block of b == streams rows, x [b][n]:
+ * single-level forward; unless noise_estimation == VW_NOISE_FIXED the ring takes the block's |details|
+ * (all of them when n <= window_size, else window_size picks stratum by stratum, :132-191) and the
+ * level is re-estimated (:193-200); then
+ *   |threshold_multiplier - 1| < 1e-10: WaveletDenoiser.denoise(samples, method, type) (:110);
+ *   otherwise threshold = calculateThreshold(samples) * threshold_multiplier (:277-324: sigma is the
+ *   estimated level, or MAD(|details|)/0.6745 of this block when there is none; UNIVERSAL sigma*sqrt(2 ln n),
+ *   SURE 0.8 of that, MINIMAX piecewise, FIXED sigma) and WaveletDenoiser.denoiseFixed (:113-115).
+ * VW_E_UNSUPPORTED where the reference throws: FIXED without a multiplier, BAYES with one; the state
+ * has then been updated, as it has in the reference.  log_n = Math.log(n), sqrt_2_ln_n =
+ * Math.sqrt(2.0 * Math.log(n)) from the host's libm (negative: the library computes them).
+ * y [b][n] out (may alias x); thresholds_out (may be NULL) receives [b].  Calls on one state must not
+ * overlap.  The _dev variant's workspace is vw_wavelet_denoise_workspace_bytes(b, n, 1) bytes or NULL/0. */
+int32_t vw_streaming_denoise_batch(vw_ctx *ctx, vw_stream_state *state, const double *x, int64_t b, int64_t n,
+                                   const double *h, int32_t lh, const double *g, int32_t lg,
+                                   const double *hr, int32_t lhr, const double *gr, int32_t lgr,
+                                   int32_t boundary, uint32_t flags, int32_t method, int32_t soft,
+                                   double threshold_multiplier, int32_t noise_estimation, double log_n,
+                                   double sqrt_2_ln_n, double *y, double *thresholds_out);
+int32_t vw_streaming_denoise_batch_dev(vw_ctx *ctx, vw_stream_state *state, const double *x_dev, int64_t b,
+                                       int64_t n, const double *h, int32_t lh, const double *g, int32_t lg,
+                                       const double *hr, int32_t lhr, const double *gr, int32_t lgr,
+                                       int32_t boundary, uint32_t flags, int32_t method, int32_t soft,
+                                       double threshold_multiplier, int32_t noise_estimation, double log_n,
+                                       double sqrt_2_ln_n, double *y_dev, double *thresholds_out_dev,
+                                       void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- structure-of-arrays batch ---------------------------------------------- */
 
 /* BatchSIMDMODWT.batchMODWTSoA(soaSignals, soaApprox, soaDetail, wavelet, batchSize, signalLength)

@@ -212,6 +212,57 @@ def wavelet_denoise_batch(x, wavelet, levels, method, soft=True, boundary=PERIOD
     return int(st), out, thr
 
 
+NOISE_MAD, NOISE_STD, NOISE_FIXED = 0, 1, 2
+
+
+class StreamingDenoiserState:
+    """State of B parallel MODWTStreamingDenoiser instances (modwt/streaming/MODWTStreamingDenoiser.java:50-54):
+    the |detail| ring per stream, the common ring position and the estimated noise level per stream."""
+
+    def __init__(self, streams, window_size):
+        self.window = np.zeros((streams, window_size))
+        self.index = 0
+        self.level = np.zeros(streams)
+        self.samples_processed = 0
+
+
+def streaming_denoise_batch(state, x, wavelet, method=UNIVERSAL, soft=True, multiplier=1.0, estimation=NOISE_MAD,
+                            boundary=PERIODIC):
+    """MODWTStreamingDenoiser.denoise (:93-127) of one block per stream; updates `state` in place.
+    Returns (status, denoised [B][n], thresholds [B])."""
+    x = _f64(x)
+    b, n = x.shape
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    out = np.empty((b, n))
+    thr = np.full(b, np.nan)
+    idx = C.c_int64(state.index)
+    w = state.window.shape[1]
+    st = lib().vwo_streaming_denoise_batch(_p(x), C.c_int64(b), C.c_int64(n), _p(h), C.c_int(h.size), _p(g), C.c_int(g.size),
+                                          _p(hr), C.c_int(hr.size), _p(gr), C.c_int(gr.size), C.c_int(boundary),
+                                          C.c_int(method), C.c_int(1 if soft else 0), C.c_double(multiplier),
+                                          C.c_int(estimation), _p(state.window), C.c_int64(w), C.byref(idx), _p(state.level),
+                                          _p(out), _p(thr))
+    state.index = idx.value
+    if st == 0:
+        state.samples_processed += n
+    return int(st), out, thr
+
+
+def stream_mad(values):
+    v = _f64(values)
+    f = lib().vwo_stream_mad
+    f.restype = C.c_double
+    return float(f(_p(v), C.c_int64(v.size)))
+
+
+def stream_std(values):
+    v = _f64(values)
+    f = lib().vwo_stream_std
+    f.restype = C.c_double
+    return float(f(_p(v), C.c_int64(v.size)))
+
+
 def apply_threshold(coeffs, threshold, soft):
     c = _f64(coeffs).copy()
     lib().vwo_apply_threshold(_p(c), C.c_int64(c.size), C.c_double(threshold), C.c_int(1 if soft else 0))

@@ -597,6 +597,199 @@ int vwo_wavelet_denoise_batch(const double *x, int64_t b, int64_t n, int levels,
 }
 
 /* ------------------------------------------------------------------------ */
+/* modwt/streaming/MODWTStreamingDenoiser.java: block-by-block denoiser with a noise window */
+/* ------------------------------------------------------------------------ */
+/* The reference's tests for this class hold properties only (lengths, "noise level is positive",
+ * "multipliers change the result"), no golden values: parity of this part is UNPINNED beyond the
+ * single-level WaveletDenoiser path underneath it, which is pinned. */
+
+/* util/MathUtils.java:95-112 (median): an order statistic, so a sort gives what quickSelect gives */
+static double median_of(const double *v, int64_t n) {
+    double *a = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(a, v, sizeof(double) * (size_t)n);
+    qsort(a, (size_t)n, sizeof(double), cmp_double);
+    double m = (n % 2 == 1) ? a[n / 2] : (a[n / 2 - 1] + a[n / 2]) / 2.0;
+    free(a);
+    return m;
+}
+
+/* MODWTStreamingDenoiser.java:211-241 (calculateMAD) over util/MathUtils.java:122-138
+ * (medianAbsoluteDeviation): median(|v_i - median(v)|); 0 when no entry is finite or every finite
+ * entry is zero.  Meaningful for finite input only (an order statistic over NaN has no defined value). */
+double vwo_stream_mad(const double *values, int64_t n) {
+    int64_t valid = 0;
+    int has_data = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (isfinite(values[i])) {
+            valid++;
+            if (values[i] != 0.0) has_data = 1;
+        }
+    if (valid == 0 || !has_data) return 0.0;
+    double med = median_of(values, n);
+    double *dev = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) dev[i] = fabs(values[i] - med);
+    double mad = median_of(dev, n);
+    free(dev);
+    return mad;
+}
+
+/* MODWTStreamingDenoiser.java:249-268 (calculateSTD) over util/MathUtils.java:234-258 */
+double vwo_stream_std(const double *values, int64_t n) {
+    int64_t valid = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (isfinite(values[i])) valid++;
+    if (valid < 2) return 0.0;
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; i++) sum += values[i];
+    double mean = sum / (double)n;
+    double ssd = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double diff = values[i] - mean;
+        ssd += diff * diff;
+    }
+    return sqrt(ssd / (double)(n - 1));
+}
+
+/* MODWTStreamingDenoiser.java:132-201 (updateNoiseEstimation): writes |detail| samples into the ring
+ * `window` (all of them when there are at most `w`, else a stratified pick of exactly `w`), then
+ * re-estimates the noise level.  estimation: 0 MAD, 1 STD. */
+void vwo_stream_update_noise(const double *details, int64_t n, double *window, int64_t w, int64_t *index,
+                             int estimation, double *level) {
+    int64_t wi = *index;
+    if (n <= w) {
+        for (int64_t i = 0; i < n; i++) {
+            window[wi] = fabs(details[i]);
+            wi = (wi + 1) % w;
+        }
+    } else {
+        int64_t strata = w < 10 ? w : 10;
+        int64_t per = w / strata, extra = w % strata, size = n / strata;
+        int64_t taken = 0;
+        for (int64_t s = 0; s < strata; s++) {
+            int64_t start = s * size;
+            int64_t end = (s == strata - 1) ? n : (s + 1) * size;
+            int64_t take = per + (s < extra ? 1 : 0);
+            if (take > 0) {
+                int64_t len = end - start;
+                int64_t step = len / take > 1 ? len / take : 1;
+                for (int64_t i = 0; i < take && taken < w; i++) {
+                    int64_t idx = start + (i * step) % len;
+                    if (idx < n) {
+                        window[wi] = fabs(details[idx]);
+                        wi = (wi + 1) % w;
+                        taken++;
+                    }
+                }
+            }
+        }
+        int64_t remaining = w - taken;
+        if (remaining > 0) {
+            int64_t from = n - remaining > 0 ? n - remaining : 0;
+            for (int64_t i = from; i < n && taken < w; i++) {
+                window[wi] = fabs(details[i]);
+                wi = (wi + 1) % w;
+                taken++;
+            }
+        }
+    }
+    *index = wi;
+    if (estimation == 0)
+        *level = vwo_stream_mad(window, w) / 0.6745;
+    else if (estimation == 1)
+        *level = vwo_stream_std(window, w);
+}
+
+/* MODWTStreamingDenoiser.java:277-324 (calculateThreshold) given the detail band of the block.
+ * method: 0 UNIVERSAL, 1 SURE, 2 MINIMAX, 4 FIXED; NaN for BAYES (3) and unknown, where the reference
+ * throws IllegalArgumentException. */
+double vwo_stream_base_threshold(const double *details, int64_t n, double level, int estimation, int method) {
+    double sigma = level;
+    if (sigma <= 0.0 || estimation == 2) {
+        double *a = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int64_t i = 0; i < n; i++) a[i] = fabs(details[i]);
+        sigma = vwo_stream_mad(a, n) / 0.6745;
+        free(a);
+    }
+    switch (method) {
+        case 0:
+            return sigma * sqrt(2.0 * log((double)n));
+        case 1:
+            return sigma * sqrt(2.0 * log((double)n)) * 0.8;
+        case 2: {
+            double logN = log((double)n);
+            if (n <= 32) return 0.0;
+            if (n <= 64) return sigma * (0.3936 + 0.1829 * logN);
+            return sigma * (0.4745 + 0.1148 * logN);
+        }
+        case 4:
+            return sigma;
+        default:
+            return NAN;
+    }
+}
+
+/* MODWTStreamingDenoiser.java:93-127 (denoise) for one block of one stream.  State: window[w], *index,
+ * *level (all updated in place; untouched when estimation == 2, FIXED).  Returns 0, or 105 where the
+ * reference throws for the method (FIXED without a multiplier; BAYES or unknown with one). */
+int vwo_streaming_denoise(const double *x, int64_t n, const double *h, int lh, const double *g, int lg,
+                          const double *hr, int lhr, const double *gr, int lgr, int boundary, int method,
+                          int soft, double multiplier, int estimation, double *window, int64_t w,
+                          int64_t *index, double *level, double *out, double *threshold_out) {
+    double *approx = (double *)malloc(sizeof(double) * (size_t)n * 2);
+    double *detail = approx + n;
+    vwo_modwt_forward(x, n, h, lh, g, lg, boundary, approx, detail);
+    if (estimation != 2) vwo_stream_update_noise(detail, n, window, w, index, estimation, level);
+    int st;
+    if (fabs(multiplier - 1.0) < 1e-10) {
+        if (method < 0 || method > 3) {
+            st = 105;
+        } else {
+            st = vwo_wavelet_denoise(x, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, method, 0.0, soft, out,
+                                     threshold_out);
+        }
+    } else {
+        double base = vwo_stream_base_threshold(detail, n, *level, estimation, method);
+        if (method == 3 || method < 0 || method > 4) {
+            st = 105;
+        } else {
+            double adjusted = base * multiplier;
+            st = vwo_wavelet_denoise(x, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, 4, adjusted, soft, out,
+                                     threshold_out);
+        }
+    }
+    free(approx);
+    return st;
+}
+
+/* b independent streams, one block each: x[b][n], window[b][w], level[b]; the ring position is common
+ * to the streams because every stream receives blocks of the same length */
+int vwo_streaming_denoise_batch(const double *x, int64_t b, int64_t n, const double *h, int lh,
+                                const double *g, int lg, const double *hr, int lhr, const double *gr,
+                                int lgr, int boundary, int method, int soft, double multiplier,
+                                int estimation, double *window, int64_t w, int64_t *index, double *level,
+                                double *out, double *thresholds_out /* [b] or NULL */) {
+    int status = 0;
+    int64_t next = *index;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < b; i++) {
+        int64_t wi = *index;
+        int st = vwo_streaming_denoise(x + i * n, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, method, soft,
+                                       multiplier, estimation, window + i * w, w, &wi, level + i,
+                                       out + i * n, thresholds_out ? thresholds_out + i : NULL);
+        if (i == 0) {
+#pragma omp critical
+            next = wi;
+        }
+        if (st != 0) {
+#pragma omp critical
+            status = st;
+        }
+    }
+    *index = next;
+    return status;
+}
+
+/* ------------------------------------------------------------------------ */
 /* modwt/BatchSIMDMODWT.java (structure-of-arrays batch) and ParallelMultiLevelMODWT.java */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,195 @@
+"""CPU: the oracle's restatement of modwt/streaming/MODWTStreamingDenoiser.java against a line-by-line
+Python re-reading of the same Java methods and against the properties the reference's own tests assert
+(src/test/.../modwt/streaming/MODWTStreamingDenoiserNoiseWindowTest.java, ...ThresholdMultiplierTest.java,
+...OverflowTest.java).  Those tests hold no numeric golden outputs, so this part of the oracle is pinned by
+formula only."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from vectorwave_amd.wavelets import get_wavelet
+
+
+def _py_median(v):
+    a = sorted(v)
+    n = len(a)
+    return a[n // 2] if n % 2 == 1 else (a[n // 2 - 1] + a[n // 2]) / 2.0
+
+
+def _py_mad(v):
+    if not any(x != 0.0 for x in v):
+        return 0.0
+    m = _py_median(v)
+    return _py_median([abs(x - m) for x in v])
+
+
+def _py_std(v):
+    n = len(v)
+    s = 0.0
+    for x in v:
+        s += x
+    mean = s / n
+    q = 0.0
+    for x in v:
+        q += (x - mean) * (x - mean)
+    return math.sqrt(q / (n - 1))
+
+
+def _py_window_update(details, window, index):
+    """MODWTStreamingDenoiser.java:140-191, statement by statement"""
+    n, w = len(details), len(window)
+    if n <= w:
+        for d in details:
+            window[index] = abs(d)
+            index = (index + 1) % w
+        return index
+    strata = min(w, 10)
+    per, extra, size = w // strata, w % strata, n // strata
+    taken = 0
+    for s in range(strata):
+        start = s * size
+        end = n if s == strata - 1 else (s + 1) * size
+        take = per + (1 if s < extra else 0)
+        if take > 0:
+            length = end - start
+            step = max(1, length // take)
+            for i in range(take):
+                if taken >= w:
+                    break
+                idx = start + (i * step) % length
+                if idx < n:
+                    window[index] = abs(details[idx])
+                    index = (index + 1) % w
+                    taken += 1
+    remaining = w - taken
+    if remaining > 0:
+        for i in range(max(0, n - remaining), n):
+            if taken >= w:
+                break
+            window[index] = abs(details[i])
+            index = (index + 1) % w
+            taken += 1
+    return index
+
+
+def _blocks(streams, n, count, seed, noise=0.1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(count * n).reshape(count, n)
+    clean = np.sin(2 * np.pi * t / 32.0)
+    return clean[:, None, :] + noise * rng.standard_normal((count, streams, n))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 101])
+def test_mad_and_std_match_the_formulas(n):
+    rng = np.random.default_rng(n)
+    v = np.abs(rng.standard_normal(n))
+    assert o.stream_mad(v) == _py_mad(v.tolist())
+    if n >= 2:
+        assert o.stream_std(v) == _py_std(v.tolist())
+    else:
+        assert o.stream_std(v) == 0.0
+    assert o.stream_mad(np.zeros(n)) == 0.0
+
+
+@pytest.mark.parametrize("n,w", [(64, 1024), (256, 1024), (480, 100), (1000, 7), (4096, 512), (300, 300), (301, 300),
+                                 (2048, 1024), (50, 3), (37, 10), (45, 11)])
+@pytest.mark.parametrize("est", [o.NOISE_MAD, o.NOISE_STD])
+def test_window_update_follows_the_java_loops(n, w, est):
+    wv = get_wavelet("db4")
+    state = o.StreamingDenoiserState(2, w)
+    win = [[0.0] * w, [0.0] * w]
+    index = 0
+    xs = _blocks(2, n, 4, seed=n + w)
+    for blk in xs:
+        st, _, _ = o.streaming_denoise_batch(state, blk, wv, estimation=est)
+        assert st == 0
+        det = o.modwt_forward_batch(blk, wv)[:, 0, :]
+        for r in range(2):
+            nxt = _py_window_update(det[r].tolist(), win[r], index)
+        index = nxt
+        assert state.index == index
+        assert np.array_equal(state.window, np.array(win))
+        for r in range(2):
+            want = _py_mad(win[r]) / 0.6745 if est == o.NOISE_MAD else _py_std(win[r])
+            assert state.level[r] == want
+    assert state.samples_processed == 4 * n
+
+
+def test_unit_multiplier_is_the_plain_denoiser():
+    # :108-110: with multiplier 1 the block goes through WaveletDenoiser.denoise unchanged
+    wv = get_wavelet("db4")
+    state = o.StreamingDenoiserState(3, 256)
+    for blk in _blocks(3, 200, 3, seed=3):
+        for method in (o.UNIVERSAL, o.SURE, o.MINIMAX, o.BAYES):
+            st, got, thr = o.streaming_denoise_batch(state, blk, wv, method=method)
+            st2, want, want_thr = o.wavelet_denoise_batch(blk, wv, 0, method)
+            assert st == 0 and st2 == 0
+            assert np.array_equal(got, want) and np.array_equal(thr, want_thr[:, 0])
+
+
+@pytest.mark.parametrize("method,factor", [(o.UNIVERSAL, 1.0), (o.SURE, 0.8)])
+def test_multiplier_path_thresholds(method, factor):
+    # :277-324 with an estimated level: threshold = level * sqrt(2 ln n) [* 0.8] * multiplier
+    wv = get_wavelet("db4")
+    n = 128
+    state = o.StreamingDenoiserState(2, 512)
+    for blk in _blocks(2, n, 3, seed=9):
+        st, got, thr = o.streaming_denoise_batch(state, blk, wv, method=method, multiplier=1.5)
+        assert st == 0
+        det = o.modwt_forward_batch(blk, wv)[:, 0, :]
+        for r in range(2):
+            # a ring that is still mostly zeros has MAD 0: the block's own details give sigma then (:282-293)
+            sigma = state.level[r] if state.level[r] > 0 else _py_mad(np.abs(det[r]).tolist()) / 0.6745
+            base = sigma * math.sqrt(2.0 * math.log(n))
+            if method == o.SURE:
+                base = base * 0.8
+            assert thr[r] == base * 1.5
+        st2, want, _ = o.wavelet_denoise_batch(blk[:1], wv, 0, o.FIXED, fixed_threshold=float(thr[0]))
+        assert np.array_equal(got[0], want[0])
+
+
+def test_multiplier_path_minimax_fixed_and_fixed_estimation():
+    wv = get_wavelet("haar")
+    for n, want_fn in ((32, lambda s, ln: 0.0), (64, lambda s, ln: s * (0.3936 + 0.1829 * ln)),
+                       (100, lambda s, ln: s * (0.4745 + 0.1148 * ln))):
+        state = o.StreamingDenoiserState(1, 64)
+        blk = _blocks(1, n, 1, seed=n)[0]
+        st, _, thr = o.streaming_denoise_batch(state, blk, wv, method=o.MINIMAX, multiplier=2.0)
+        assert st == 0 and thr[0] == want_fn(state.level[0], math.log(n)) * 2.0
+    # FIXED method: the level itself; FIXED estimation: sigma from this block's own details, state untouched
+    state = o.StreamingDenoiserState(1, 64)
+    blk = _blocks(1, 100, 1, seed=4)[0]
+    st, _, thr = o.streaming_denoise_batch(state, blk, wv, method=o.FIXED, multiplier=0.5, estimation=o.NOISE_FIXED)
+    d = o.modwt_forward_batch(blk, wv)[0, 0]
+    assert st == 0 and thr[0] == _py_mad(np.abs(d).tolist()) / 0.6745 * 0.5
+    assert state.index == 0 and not state.window.any() and state.level[0] == 0.0
+
+
+def test_methods_the_reference_rejects():
+    wv = get_wavelet("db4")
+    state = o.StreamingDenoiserState(1, 64)
+    blk = _blocks(1, 50, 1, seed=1)[0]
+    assert o.streaming_denoise_batch(state, blk, wv, method=o.FIXED)[0] == 105          # denoise(..., FIXED, ...) throws
+    assert o.streaming_denoise_batch(state, blk, wv, method=o.BAYES, multiplier=2.0)[0] == 105  # switch default branch
+
+
+def test_reference_test_properties():
+    # NoiseWindowTest.testNoiseEstimationConsistency: two denoisers fed the same blocks agree
+    wv = get_wavelet("db4")
+    xs = _blocks(1, 256, 5, seed=2, noise=0.05)
+    s1, s2 = o.StreamingDenoiserState(1, 128), o.StreamingDenoiserState(1, 128)
+    for blk in xs:
+        a = o.streaming_denoise_batch(s1, blk, wv, multiplier=1.2)[1]
+        b = o.streaming_denoise_batch(s2, blk, wv, multiplier=1.2)[1]
+        assert np.array_equal(a, b)
+    # OverflowTest.testNoiseEstimationConsistency: level positive and of the order of the injected noise
+    assert 0 < s1.level[0] < 0.2
+    # ThresholdMultiplierTest.testThresholdMultiplierEffect: larger multipliers remove more energy
+    energies = []
+    for mult in (0.25, 0.5, 3.0):
+        st = o.StreamingDenoiserState(1, 128)
+        y = o.streaming_denoise_batch(st, xs[0], wv, multiplier=mult)[1]
+        energies.append(float((y * y).sum()))
+    assert energies[0] > energies[1] > energies[2]  # 3.0 removes the whole detail band

@@ -108,6 +108,35 @@ def main():
                 print(name, res[name], flush=True)
             del x, y
             torch.cuda.empty_cache()
+    # MODWTStreamingDenoiser: 8192 lock-step streams, one 480-sample block each per call, ring of 1024 per stream
+    if not args.only or "N2" in args.only:
+        import numpy as np
+        from vectorwave_amd.wavelets import get_wavelet
+        rows, n, window = 8192, 480, 1024
+        w = get_wavelet("db4")
+        dp = C.POINTER(C.c_double)
+        taps = [np.ascontiguousarray(t, dtype=np.float64) for t in (w.dec_lo, w.dec_hi, w.rec_lo, w.rec_hi)]
+        x = dev_signals(rows, n, seed=7, noise=0.3)
+        y = torch.empty_like(x)
+        sp = C.c_void_p(stream.cuda_stream)
+        for est, mult, label in ((0, 1.0, "MAD"), (0, 1.5, "MAD x1.5"), (1, 1.5, "STD x1.5"), (2, 1.0, "FIXED")):
+            state = C.c_void_p()
+            assert ctx.lib.vw_stream_state_create(ctx.handle, rows, window, C.byref(state)) == 0
+
+            def run():
+                st = ctx.lib.vw_streaming_denoise_batch_dev(
+                    ctx.handle, state, C.c_void_p(x.data_ptr()), rows, n, taps[0].ctypes.data_as(dp), taps[0].size,
+                    taps[1].ctypes.data_as(dp), taps[1].size, taps[2].ctypes.data_as(dp), taps[2].size,
+                    taps[3].ctypes.data_as(dp), taps[3].size, 0, 0, 0, 1, mult, est, -1.0, -1.0, C.c_void_p(y.data_ptr()),
+                    None, None, 0, sp)
+                assert st == 0, ctx.last_error()
+            ms = timed(run)
+            torch.cuda.synchronize()
+            ctx.lib.vw_stream_state_destroy(ctx.handle, state)
+            name = "N2 db4 MODWTStreamingDenoiser %dx%d ring %d %s" % (rows, n, window, label)
+            res[name] = {"block_ms": round(ms, 4), "Gsamples_per_s": round(rows * n / (ms * 1e-3) / 1e9, 3),
+                         "blocks_per_s": round(rows / (ms * 1e-3))}
+            print(name, res[name], flush=True)
     # BatchSIMDMODWT.batchMODWTSoA: single-level transform of a sample-major batch (24 B/sample)
     if not args.only or "N3" in args.only:
         from vectorwave_amd.wavelets import get_wavelet

@@ -4,7 +4,8 @@ Host mirror of the reference's MODWTTransform / MultiLevelMODWTTransform /
 VectorWaveSwtAdapter API over libvwgpu.so (hand-written gfx950 HIP kernels
 behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
-from .api import (BatchSIMDMODWT, BoundaryMode, InvalidArgumentException, InvalidSignalException, MODWTResult, MODWTTransform,
+from .api import (BatchSIMDMODWT, BoundaryMode, IllegalStateException, InvalidArgumentException, InvalidSignalException, MODWTResult,
+                  MODWTStreamingDenoiser, MODWTTransform, NoiseEstimation,
                   MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult, ParallelMultiLevelMODWT,
                   ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
                   WaveletTransformException)
@@ -15,4 +16,5 @@ __all__ = [
     "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
     "WaveletDenoiser", "ThresholdMethod", "ThresholdType", "BatchSIMDMODWT", "ParallelMultiLevelMODWT",
+    "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException",
 ]

@@ -41,6 +41,10 @@ VW_THRESHOLD_MINIMAX = 2
 VW_THRESHOLD_BAYES = 3
 VW_THRESHOLD_FIXED = 4
 
+VW_NOISE_MAD = 0
+VW_NOISE_STD = 1
+VW_NOISE_FIXED = 2
+
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _vp = C.c_void_p
@@ -87,6 +91,18 @@ SIGNATURES = {
     "vw_batch_modwt_soa": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _vp, _vp]),
     "vw_batch_modwt_soa_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _vp, _vp,
                                            _vp]),
+    "vw_stream_state_create": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.POINTER(_vp)]),
+    "vw_stream_state_destroy": (C.c_int32, [_vp, _vp]),
+    "vw_stream_state_noise_levels": (C.c_int32, [_vp, _vp, _vp]),
+    "vw_stream_state_window": (C.c_int32, [_vp, _vp, _vp, _i64p]),
+    "vw_stream_state_samples_processed": (C.c_int64, [_vp]),
+    "vw_streaming_denoise_batch": (C.c_int32, [_vp, _vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32, _dp,
+                                               C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                               C.c_double, C.c_int32, C.c_double, C.c_double, _vp, _vp]),
+    "vw_streaming_denoise_batch_dev": (C.c_int32, [_vp, _vp, _vp, C.c_int64, C.c_int64, _dp, C.c_int32, _dp, C.c_int32,
+                                                   _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32,
+                                                   C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, _vp, _vp,
+                                                   _vp, C.c_size_t, _vp]),
     "vw_transpose": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
     "vw_transpose_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),

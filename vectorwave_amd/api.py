@@ -801,6 +801,210 @@ class WaveletDenoiser:
 
 
 # ---------------------------------------------------------------------------
+# modwt/streaming/MODWTStreamingDenoiser.java
+# ---------------------------------------------------------------------------
+
+class NoiseEstimation(enum.IntEnum):
+    """modwt/streaming/MODWTStreamingDenoiser.java:58-65"""
+    MAD = N.VW_NOISE_MAD
+    STD = N.VW_NOISE_STD
+    FIXED = N.VW_NOISE_FIXED
+
+
+class IllegalStateException(RuntimeError):
+    """java.lang.IllegalStateException"""
+
+
+class MODWTStreamingDenoiser:
+    """Mirror of modwt/streaming/MODWTStreamingDenoiser.java: denoises a signal block by block while a ring of
+    |detail| samples tracks the noise level.  `streams(k)` on the builder (not in the reference) runs k such
+    denoisers in lock step, one block per stream per call, with their rings resident in GPU memory."""
+
+    NoiseEstimation = NoiseEstimation
+
+    class Builder:
+        """:367-469, same defaults (:368-375) and the same argument checks"""
+
+        def __init__(self):
+            self._wavelet = "db4"
+            self._boundaryMode = BoundaryMode.PERIODIC
+            self._bufferSize = 256
+            self._thresholdType = ThresholdType.SOFT
+            self._thresholdMethod = ThresholdMethod.UNIVERSAL
+            self._thresholdMultiplier = 1.0
+            self._noiseEstimation = NoiseEstimation.MAD
+            self._noiseWindowSize = 1024
+            self._streams = 1
+            self._ctx = None
+
+        def wavelet(self, wavelet):
+            if wavelet is None:
+                raise InvalidArgumentException("Wavelet cannot be null")
+            self._wavelet = wavelet
+            return self
+
+        def boundaryMode(self, boundaryMode):
+            if boundaryMode is None:
+                raise InvalidArgumentException("Boundary mode cannot be null")
+            self._boundaryMode = BoundaryMode(boundaryMode)
+            return self
+
+        def bufferSize(self, bufferSize):
+            if bufferSize <= 0:
+                raise InvalidArgumentException("Buffer size must be positive")
+            self._bufferSize = int(bufferSize)
+            return self
+
+        def thresholdType(self, thresholdType):
+            if thresholdType is None:
+                raise InvalidArgumentException("Threshold type cannot be null")
+            self._thresholdType = ThresholdType(thresholdType)
+            return self
+
+        def thresholdMethod(self, thresholdMethod):
+            if thresholdMethod is None:
+                raise InvalidArgumentException("Threshold method cannot be null")
+            self._thresholdMethod = ThresholdMethod(thresholdMethod)
+            return self
+
+        def thresholdMultiplier(self, thresholdMultiplier):
+            if not thresholdMultiplier > 0:
+                raise InvalidArgumentException("Threshold multiplier must be positive")
+            self._thresholdMultiplier = float(thresholdMultiplier)
+            return self
+
+        def noiseEstimation(self, noiseEstimation):
+            if noiseEstimation is None:
+                raise InvalidArgumentException("Noise estimation cannot be null")
+            self._noiseEstimation = NoiseEstimation(noiseEstimation)
+            return self
+
+        def noiseWindowSize(self, noiseWindowSize):
+            if noiseWindowSize <= 0:
+                raise InvalidArgumentException("Noise window size must be positive")
+            self._noiseWindowSize = int(noiseWindowSize)
+            return self
+
+        def streams(self, streams):
+            if streams <= 0:
+                raise InvalidArgumentException("Stream count must be positive")
+            self._streams = int(streams)
+            return self
+
+        def context(self, ctx):
+            self._ctx = ctx
+            return self
+
+        def build(self):
+            return MODWTStreamingDenoiser(self)
+
+    def __init__(self, builder: "MODWTStreamingDenoiser.Builder"):
+        # :67-83
+        self.wavelet = _as_wavelet(builder._wavelet)
+        self.boundaryMode = builder._boundaryMode
+        self.bufferSize = builder._bufferSize
+        self.thresholdType = builder._thresholdType
+        self.thresholdMethod = builder._thresholdMethod
+        self.thresholdMultiplier = builder._thresholdMultiplier
+        self.noiseEstimation = builder._noiseEstimation
+        self.noiseWindowSize = builder._noiseWindowSize
+        self.streams = builder._streams
+        self._ctx = builder._ctx if builder._ctx is not None else N.default_context()
+        self._closed = False
+        self._final_samples = 0
+        self._subscribers = []
+        self._state = C.c_void_p()
+        st = self._ctx.lib.vw_stream_state_create(self._ctx.handle, self.streams, self.noiseWindowSize, C.byref(self._state))
+        _raise_for_status(self._ctx, st)
+
+    def denoise(self, samples):
+        """:93-127.  One block: a 1-D array for a single stream, or [streams][n] for lock-step streams."""
+        if self._closed:
+            raise IllegalStateException("Denoiser is closed")
+        if samples is None:
+            raise InvalidArgumentException("Samples cannot be null or empty")
+        x = np.ascontiguousarray(np.asarray(samples, dtype=np.float64))
+        if x.size == 0:
+            raise InvalidArgumentException("Samples cannot be null or empty")
+        single = x.ndim == 1
+        if single:
+            x = x.reshape(1, -1)
+        if x.ndim != 2 or x.shape[0] != self.streams:
+            raise InvalidArgumentException("expected one block per stream: %d rows" % self.streams)
+        ctx = self._ctx
+        bad = C.c_int64(-1)
+        _raise_for_status(ctx, ctx.lib.vw_first_non_finite(ctx.handle, _vp(x), x.size, C.byref(bad)))
+        b, n = x.shape
+        w = self.wavelet
+        h, g, hr, gr = _taps(w.dec_lo), _taps(w.dec_hi), _taps(w.rec_lo), _taps(w.rec_hi)
+        out = np.empty((b, n))
+        log_n = math.log(n)
+        st = ctx.lib.vw_streaming_denoise_batch(ctx.handle, self._state, _vp(x), b, n, _dp(h), h.size, _dp(g), g.size,
+                                                _dp(hr), hr.size, _dp(gr), gr.size, int(self.boundaryMode), 0,
+                                                int(self.thresholdMethod),
+                                                1 if int(self.thresholdType) == int(ThresholdType.SOFT) else 0,
+                                                self.thresholdMultiplier, int(self.noiseEstimation), log_n,
+                                                math.sqrt(2.0 * log_n), _vp(out), None)
+        _raise_for_status(ctx, st)
+        result = out[0] if single else out
+        for s in self._subscribers:
+            item = result.copy()  # :122-124: subscribers receive a clone
+            (s.onNext if hasattr(s, "onNext") else s)(item)
+        return result
+
+    def getEstimatedNoiseLevel(self):
+        """:332-334; an array with one level per stream when there are several"""
+        lv = np.empty(self.streams)
+        _raise_for_status(self._ctx, self._ctx.lib.vw_stream_state_noise_levels(self._ctx.handle, self._state, _vp(lv)))
+        return float(lv[0]) if self.streams == 1 else lv
+
+    def getNoiseWindow(self):
+        """Copy of the |detail| rings [streams][noiseWindowSize] and the ring position (for tests)."""
+        win = np.empty((self.streams, self.noiseWindowSize))
+        idx = C.c_int64(0)
+        _raise_for_status(self._ctx, self._ctx.lib.vw_stream_state_window(self._ctx.handle, self._state, _vp(win), C.byref(idx)))
+        return win, int(idx.value)
+
+    def getSamplesProcessed(self):
+        """:341-343"""
+        if not self._state:
+            return self._final_samples
+        return int(self._ctx.lib.vw_stream_state_samples_processed(self._state))
+
+    def subscribe(self, subscriber):
+        """:346-348: `subscriber` is a callable or has onNext(array)"""
+        self._subscribers.append(subscriber)
+
+    def close(self):
+        """:351-355"""
+        if not self._closed:
+            self._closed = True
+            for s in self._subscribers:
+                if hasattr(s, "onComplete"):
+                    s.onComplete()
+            self._subscribers = []
+            if self._state:
+                self._final_samples = int(self._ctx.lib.vw_stream_state_samples_processed(self._state))
+                self._ctx.lib.vw_stream_state_destroy(self._ctx.handle, self._state)
+                self._state = C.c_void_p()
+
+    def isClosed(self):
+        return self._closed
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
 # modwt/BatchSIMDMODWT.java and modwt/ParallelMultiLevelMODWT.java
 # ---------------------------------------------------------------------------
 

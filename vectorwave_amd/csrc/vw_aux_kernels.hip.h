@@ -163,7 +163,8 @@ struct KeySrc {
 };
 
 // Returns the key of rank k (0-based) among n keys; all threads get the result.
-__device__ unsigned long long radix_select(const KeySrc& src, int64_t n, int64_t k, unsigned* hist /*256*/,
+template <typename Src>
+__device__ unsigned long long radix_select(const Src& src, int64_t n, int64_t k, unsigned* hist /*256*/,
                                            unsigned* wsum /*4*/, unsigned long long* bcast /*2*/) {
     const int tid = threadIdx.x;
     unsigned long long prefix = 0;
@@ -198,6 +199,43 @@ __device__ unsigned long long radix_select(const KeySrc& src, int64_t n, int64_t
     return prefix;
 }
 
+// Median of n non-negative keys the way the reference takes it from a sorted copy: the middle element,
+// or the mean of the two middle elements for even n.  All threads call it and all get the result.
+template <typename Src>
+__device__ double median_select(const Src& src, int64_t n, unsigned* hist /*256*/, unsigned* wsum /*4*/,
+                                unsigned long long* bcast /*2*/, unsigned long long* red /*kThreads*/) {
+    const int tid = threadIdx.x;
+    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+    const unsigned long long v1 = radix_select(src, n, k1, hist, wsum, bcast);
+    if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
+    // rank k1+1: v1 again if at least k1+2 keys are <= v1, else the smallest key above v1
+    unsigned long long le = 0, above = ~0ull;
+    for (int64_t i = tid; i < n; i += kThreads) {
+        const unsigned long long key = src.get(i);
+        if (key <= v1)
+            ++le;
+        else if (key < above)
+            above = key;
+    }
+    red[tid] = le;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const unsigned long long le_total = red[0];
+    __syncthreads();
+    red[tid] = above;
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        if (tid < w && red[tid + w] < red[tid]) red[tid] = red[tid + w];
+        __syncthreads();
+    }
+    const unsigned long long v2 = (static_cast<int64_t>(le_total) >= k1 + 2) ? v1 : red[0];
+    __syncthreads();
+    return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
+}
+
 struct MedianArgs {
     const double* d1;      // band d_1 of row r at d1 + r*row_stride
     int64_t row_stride;
@@ -229,42 +267,196 @@ __global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianAr
         src.lds = keys;
         __syncthreads();
     }
-    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
-    const unsigned long long v1 = radix_select(src, n, k1, hist, wsum, bcast);
-    double median;
-    if (n % 2 != 0) {
-        median = __longlong_as_double(static_cast<long long>(v1));
-    } else {
-        // rank k1+1: v1 again if at least k1+2 keys are <= v1, else the smallest key above v1
-        unsigned long long le = 0, above = ~0ull;
-        for (int64_t i = tid; i < n; i += kThreads) {
-            const unsigned long long key = src.get(i);
-            if (key <= v1)
-                ++le;
-            else if (key < above)
-                above = key;
-        }
-        red[tid] = le;
-        __syncthreads();
-        for (int w = kThreads / 2; w > 0; w >>= 1) {
-            if (tid < w) red[tid] += red[tid + w];
-            __syncthreads();
-        }
-        const unsigned long long le_total = red[0];
-        __syncthreads();
-        red[tid] = above;
-        __syncthreads();
-        for (int w = kThreads / 2; w > 0; w >>= 1) {
-            if (tid < w && red[tid + w] < red[tid]) red[tid] = red[tid + w];
-            __syncthreads();
-        }
-        const unsigned long long v2 = (static_cast<int64_t>(le_total) >= k1 + 2) ? v1 : red[0];
-        median = (__longlong_as_double(static_cast<long long>(v1)) +
-                  __longlong_as_double(static_cast<long long>(v2))) / 2.0;
-    }
+    const double median = median_select(src, n, hist, wsum, bcast, red);
     if (tid == 0) {
         const double sigma = median / 0.6745;
         a.thr_out[row] = sigma * a.sqrt_2_ln_n;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// streaming denoiser: noise window, noise level and multiplier-path threshold, one workgroup per stream
+// ---------------------------------------------------------------------------
+//
+// Every stream keeps a ring of |detail| samples.  A block writes all of its details into the ring when
+// there are at most `w` of them, else exactly `w` picked stratum by stratum (up to ten equal strata, evenly
+// spaced inside each), so the ring position after a block is the same for every stream.  The noise level is
+// MAD(ring)/0.6745 with MAD = median(|v - median(v)|), or the sample standard deviation summed in index
+// order.  With a threshold multiplier the block's threshold comes from that level (or, when there is none
+// yet, from the MAD of the block's own |details|).
+
+// key = bit pattern of | |v_i| - sub |: with sub = 0 the keys are |v_i| themselves
+struct AbsDevSrc {
+    const double* lds;
+    const double* glob;
+    double sub;
+    __device__ __forceinline__ unsigned long long get(int64_t i) const {
+        const double v = lds != nullptr ? lds[i] : glob[i];
+        return static_cast<unsigned long long>(__double_as_longlong(fabs(fabs(v) - sub))) & 0x7fffffffffffffffull;
+    }
+};
+
+struct StreamNoiseArgs {
+    const double* details;  // band d_1 of stream r at details + r*row_stride
+    int64_t row_stride;
+    int64_t n;
+    int64_t nrows;
+    double* window;         // [nrows][w]
+    int64_t w;
+    int64_t index0;         // ring position before this block
+    int32_t estimation;     // 0 MAD, 1 STD, 2 FIXED (ring and level untouched)
+    int32_t want_thr;       // 1: write thr = base threshold * multiplier
+    int32_t method;         // 0 UNIVERSAL, 1 SURE (0.8 * universal), 2 MINIMAX, 4 FIXED (sigma itself)
+    double multiplier;
+    double log_n;           // Math.log(n)
+    double sqrt_2_ln_n;     // Math.sqrt(2.0 * Math.log(n))
+    double* level;          // [nrows] in/out
+    double* thr;            // [nrows]
+    int32_t lds_cap;        // a ring or a block up to this length is copied into LDS
+};
+
+// MAD of |v_0..n-1| with the reference's guards: 0 when no entry is finite or every finite entry is zero
+__device__ double stream_mad(AbsDevSrc& src, int64_t n, unsigned* hist, unsigned* wsum, unsigned long long* bcast,
+                             unsigned long long* red) {
+    const int tid = threadIdx.x;
+    int fin = 0, nz = 0;
+    for (int64_t i = tid; i < n; i += kThreads) {
+        const double v = src.lds != nullptr ? src.lds[i] : src.glob[i];
+        if (finite_f64(v)) {
+            fin = 1;
+            if (v != 0.0) nz = 1;
+        }
+    }
+    const int any_fin = __syncthreads_or(fin);
+    const int any_nz = __syncthreads_or(nz);
+    if (!any_fin || !any_nz) return 0.0;
+    src.sub = 0.0;
+    const double med = median_select(src, n, hist, wsum, bcast, red);
+    src.sub = med;
+    return median_select(src, n, hist, wsum, bcast, red);
+}
+
+__global__ void __launch_bounds__(kThreads) k_stream_noise(const StreamNoiseArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ double2 vw_smem[];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned long long bcast[2];
+    __shared__ unsigned long long red[kThreads];
+    __shared__ double bc;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n, w = a.w;
+    const double* __restrict__ d = a.details + row * a.row_stride;
+    double* win = a.window + row * w;
+    double* stage = reinterpret_cast<double*>(vw_smem);
+    double lvl;
+
+    if (a.estimation != 2) {
+        const int64_t m = n <= w ? n : w;
+        const int64_t strata = w < 10 ? w : 10;
+        const int64_t per = w / strata, extra = w % strata, size = n / strata;
+        for (int64_t k = tid; k < m; k += kThreads) {
+            int64_t src_i = k;
+            if (n > w) {
+                // k-th pick: strata 0..extra-1 give per+1 picks each, the rest give per
+                int64_t s, i;
+                if (k < extra * (per + 1)) {
+                    s = k / (per + 1);
+                    i = k - s * (per + 1);
+                } else {
+                    const int64_t kk = k - extra * (per + 1);
+                    s = extra + kk / per;
+                    i = kk - (kk / per) * per;
+                }
+                const int64_t take = per + (s < extra ? 1 : 0);
+                const int64_t start = s * size;
+                const int64_t end = (s == strata - 1) ? n : (s + 1) * size;
+                const int64_t len = end - start;
+                const int64_t step = len / take > 1 ? len / take : 1;
+                src_i = start + (i * step) % len;
+            }
+            win[(a.index0 + k) % w] = fabs(d[src_i]);
+        }
+        __threadfence_block();
+        __syncthreads();
+        AbsDevSrc src;
+        src.glob = win;
+        src.lds = nullptr;
+        src.sub = 0.0;
+        if (w <= a.lds_cap) {
+            for (int64_t i = tid; i < w; i += kThreads) stage[i] = win[i];
+            src.lds = stage;
+            __syncthreads();
+        }
+        if (a.estimation == 0) {
+            lvl = stream_mad(src, w, hist, wsum, bcast, red) / 0.6745;
+        } else {
+            unsigned long long fin = 0;
+            for (int64_t i = tid; i < w; i += kThreads) fin += finite_f64(src.lds != nullptr ? src.lds[i] : src.glob[i]) ? 1 : 0;
+            red[tid] = fin;
+            __syncthreads();
+            for (int s = kThreads / 2; s > 0; s >>= 1) {
+                if (tid < s) red[tid] += red[tid + s];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                double r = 0.0;
+                if (red[0] >= 2) {  // fewer than two finite entries: no standard deviation
+                    const double* v = src.lds != nullptr ? src.lds : src.glob;
+                    double sum = 0.0;
+                    for (int64_t i = 0; i < w; ++i) sum += v[i];
+                    const double mean = sum / static_cast<double>(w);
+                    double ssd = 0.0;
+                    for (int64_t i = 0; i < w; ++i) {
+                        const double diff = v[i] - mean;
+                        ssd += diff * diff;
+                    }
+                    r = sqrt(ssd / static_cast<double>(w - 1));
+                }
+                bc = r;
+            }
+            __syncthreads();
+            lvl = bc;
+        }
+        if (tid == 0) a.level[row] = lvl;
+    } else {
+        lvl = a.level[row];
+    }
+    if (!a.want_thr) return;
+
+    double sigma = lvl;
+    if (sigma <= 0.0 || a.estimation == 2) {
+        __syncthreads();  // the ring's LDS copy is dead from here on
+        AbsDevSrc src;
+        src.glob = d;
+        src.lds = nullptr;
+        src.sub = 0.0;
+        if (n <= a.lds_cap) {
+            for (int64_t i = tid; i < n; i += kThreads) stage[i] = fabs(d[i]);
+            src.lds = stage;
+            __syncthreads();
+        }
+        // a global source holds signed details: the guards see the same finite / non-zero pattern and the keys take |v|
+        sigma = stream_mad(src, n, hist, wsum, bcast, red) / 0.6745;
+    }
+    if (tid == 0) {
+        double base;
+        if (a.method == 0) {
+            base = sigma * a.sqrt_2_ln_n;
+        } else if (a.method == 1) {
+            base = sigma * a.sqrt_2_ln_n * 0.8;
+        } else if (a.method == 2) {
+            if (n <= 32)
+                base = 0.0;
+            else if (n <= 64)
+                base = sigma * (0.3936 + 0.1829 * a.log_n);
+            else
+                base = sigma * (0.4745 + 0.1148 * a.log_n);
+        } else {
+            base = sigma;
+        }
+        a.thr[row] = base * a.multiplier;
     }
 }
 

@@ -1301,6 +1301,38 @@ extern "C" int32_t vw_denoiser_thresholds_batch(vw_ctx* ctx, const double* coeff
     return VW_OK;
 }
 
+// thresholds [b][levels] applied to the detail bands of coeffs, then the inverse: on load inside the inverse
+// kernels where they handle the configuration, else in place ahead of the generic per-level inverse
+static int threshold_inverse_dev(vw_ctx* ctx, double* coeffs, int64_t b, int64_t n, int levels, const double* hr, int lhr,
+                                 const double* gr, int lgr, int boundary, uint32_t tflags, int soft, const double* thr,
+                                 double* y_dev, hipStream_t s) {
+    const bool single = (tflags & VW_FLAG_SINGLE_LEVEL) != 0;
+    const int mode = soft ? 1 : 2;
+    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
+    if (!single) {
+        for (int j = 1; j <= levels; ++j) {
+            const int64_t st = static_cast<int64_t>(1) << (j - 1);
+            if (truncated_taps(lhr, st, n) != lhr || truncated_taps(lgr, st, n) != lgr) generic = true;
+        }
+    }
+    if (generic) {
+        const int64_t cnt = static_cast<int64_t>(levels) * n;
+        int64_t bx = (cnt + kThreads - 1) / kThreads;
+        if (bx > 1024) bx = 1024;
+        for (int64_t r0 = 0; r0 < b; r0 += 65535) {
+            const int64_t nr = (b - r0) < 65535 ? (b - r0) : 65535;
+            hipLaunchKernelGGL(k_threshold_rows, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nr)), dim3(kThreads), 0, s,
+                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0 * levels, static_cast<int64_t>(levels),
+                               static_cast<int64_t>(1), mode);
+        }
+        VW_HIP(ctx, hipGetLastError());
+        return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, 0, nullptr, y_dev,
+                           nullptr, s);
+    }
+    return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, mode, thr, y_dev, nullptr, s,
+                       levels, 1);
+}
+
 extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
                                                 const double* h, int32_t lh, const double* g, int32_t lg,
                                                 const double* hr, int32_t lhr, const double* gr, int32_t lgr,
@@ -1349,30 +1381,7 @@ extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev
     }
     if (thresholds_out_dev != nullptr)
         VW_HIP(ctx, hipMemcpyAsync(thresholds_out_dev, thr, static_cast<size_t>(b) * levels * 8, hipMemcpyDeviceToDevice, s));
-    const int mode = soft ? 1 : 2;
-    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
-    if (!single) {
-        for (int j = 1; j <= levels; ++j) {
-            const int64_t st = static_cast<int64_t>(1) << (j - 1);
-            if (truncated_taps(lhr, st, n) != lhr || truncated_taps(lgr, st, n) != lgr) generic = true;
-        }
-    }
-    if (generic) {
-        const int64_t cnt = static_cast<int64_t>(levels) * n;
-        int64_t bx = (cnt + kThreads - 1) / kThreads;
-        if (bx > 1024) bx = 1024;
-        for (int64_t r0 = 0; r0 < b; r0 += 65535) {
-            const int64_t nr = (b - r0) < 65535 ? (b - r0) : 65535;
-            hipLaunchKernelGGL(k_threshold_rows, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(nr)), dim3(kThreads), 0, s,
-                               coeffs + r0 * (levels + 1) * n, n, levels, thr + r0 * levels, static_cast<int64_t>(levels),
-                               static_cast<int64_t>(1), mode);
-        }
-        VW_HIP(ctx, hipGetLastError());
-        return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, 0, nullptr, y_dev,
-                           nullptr, s);
-    }
-    return inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, 0xffffffffu, mode, thr, y_dev, nullptr, s,
-                       levels, 1);
+    return threshold_inverse_dev(ctx, coeffs, b, n, levels, hr, lhr, gr, lgr, boundary, tflags, soft, thr, y_dev, s);
 }
 
 extern "C" int32_t vw_wavelet_denoise_batch(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int32_t levels,
@@ -1408,6 +1417,223 @@ extern "C" int32_t vw_wavelet_denoise_batch(vw_ctx* ctx, const double* x, int64_
                                        hipMemcpyDeviceToHost, ctx->stream));
         VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
+// MODWTStreamingDenoiser: lock-step streams with their noise windows in device memory
+// ---------------------------------------------------------------------------
+
+struct vw_stream_state {
+    int device;
+    int64_t streams, window;
+    double* win;     // [streams][window]
+    double* level;   // [streams]
+    int64_t index;   // ring position, common to the streams
+    int64_t samples; // per stream
+};
+
+extern "C" int32_t vw_stream_state_create(vw_ctx* ctx, int64_t streams, int64_t window_size, vw_stream_state** out) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (out == nullptr) return set_err(ctx, VW_E_NULL, "state pointer cannot be null");
+    *out = nullptr;
+    if (streams <= 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Stream count must be positive");
+    if (window_size <= 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Noise window size must be positive");
+    if (window_size > 0x7fffffffLL || streams > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "state too large");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    vw_stream_state* st = new (std::nothrow) vw_stream_state();
+    if (st == nullptr) return set_err(ctx, VW_E_NOMEM, "out of host memory");
+    st->device = ctx->device;
+    st->streams = streams;
+    st->window = window_size;
+    st->win = nullptr;
+    st->level = nullptr;
+    st->index = 0;
+    st->samples = 0;
+    const size_t wbytes = static_cast<size_t>(streams) * static_cast<size_t>(window_size) * 8;
+    if (hipMalloc(reinterpret_cast<void**>(&st->win), wbytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&st->level), static_cast<size_t>(streams) * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (st->win != nullptr) (void)hipFree(st->win);
+        delete st;
+        return set_err(ctx, VW_E_NOMEM, "cannot allocate %zu bytes of noise windows", wbytes);
+    }
+    hipError_t e = hipMemsetAsync(st->win, 0, wbytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(st->level, 0, static_cast<size_t>(streams) * 8, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(st->win);
+        (void)hipFree(st->level);
+        delete st;
+        return set_err(ctx, VW_E_HIP, "HIP error: %s", hipGetErrorString(e));
+    }
+    *out = st;
+    return VW_OK;
+}
+
+extern "C" int32_t vw_stream_state_destroy(vw_ctx* ctx, vw_stream_state* state) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (state == nullptr) return VW_OK;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(state->device));
+    (void)hipDeviceSynchronize();
+    (void)hipFree(state->win);
+    (void)hipFree(state->level);
+    delete state;
+    return VW_OK;
+}
+
+extern "C" int32_t vw_stream_state_noise_levels(vw_ctx* ctx, vw_stream_state* state, double* levels) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (state == nullptr || levels == nullptr) return set_err(ctx, VW_E_NULL, "state and levels cannot be null");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(state->device));
+    VW_HIP(ctx, hipDeviceSynchronize());
+    VW_HIP(ctx, hipMemcpy(levels, state->level, static_cast<size_t>(state->streams) * 8, hipMemcpyDeviceToHost));
+    return VW_OK;
+}
+
+extern "C" int32_t vw_stream_state_window(vw_ctx* ctx, vw_stream_state* state, double* window, int64_t* window_index) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (state == nullptr || window == nullptr) return set_err(ctx, VW_E_NULL, "state and window cannot be null");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(state->device));
+    VW_HIP(ctx, hipDeviceSynchronize());
+    VW_HIP(ctx, hipMemcpy(window, state->win, static_cast<size_t>(state->streams) * static_cast<size_t>(state->window) * 8,
+                          hipMemcpyDeviceToHost));
+    if (window_index != nullptr) *window_index = state->index;
+    return VW_OK;
+}
+
+extern "C" int64_t vw_stream_state_samples_processed(const vw_stream_state* state) {
+    return state != nullptr ? state->samples : 0;
+}
+
+extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* state, const double* x_dev, int64_t b,
+                                                  int64_t n, const double* h, int32_t lh, const double* g, int32_t lg,
+                                                  const double* hr, int32_t lhr, const double* gr, int32_t lgr,
+                                                  int32_t boundary, uint32_t flags, int32_t method, int32_t soft,
+                                                  double threshold_multiplier, int32_t noise_estimation, double log_n,
+                                                  double sqrt_2_ln_n, double* y_dev, double* thresholds_out_dev,
+                                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
+    const uint32_t tflags = (flags & VW_FLAG_FMA) | VW_FLAG_SINGLE_LEVEL;
+    if (ctx == nullptr) return VW_E_NULL;
+    if (state == nullptr) return set_err(ctx, VW_E_NULL, "Stream state cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Samples cannot be null or empty");
+    int rc = forward_checks(ctx, x_dev, b, n, 1, h, lh, g, lg, boundary, tflags, y_dev);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x_dev, b, n, 1, hr, lhr, gr, lgr, boundary, tflags, y_dev);
+    if (rc != VW_OK) return rc;
+    if (b != state->streams)
+        return set_err(ctx, VW_E_LENGTH_MISMATCH, "block of %lld rows given to a state of %lld streams", static_cast<long long>(b),
+                       static_cast<long long>(state->streams));
+    if (noise_estimation < VW_NOISE_MAD || noise_estimation > VW_NOISE_FIXED)
+        return set_err(ctx, VW_E_UNSUPPORTED, "Unknown noise estimation method");
+    if (!(threshold_multiplier > 0)) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold multiplier must be positive");
+    if (state->device != ctx->device) return set_err(ctx, VW_E_UNSUPPORTED, "stream state belongs to another device");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t need = vw_wavelet_denoise_workspace_bytes(b, n, 1);
+    char* wsb;
+    if (workspace_dev != nullptr) {
+        if (workspace_bytes < need) return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+        wsb = static_cast<char*>(workspace_dev);
+    } else {
+        rc = ensure(ctx, ctx->denoise_ws, need);
+        if (rc != VW_OK) return rc;
+        wsb = static_cast<char*>(ctx->denoise_ws.p);
+    }
+    const size_t cbytes = round256(static_cast<size_t>(b) * 2 * n * 8);
+    double* coeffs = reinterpret_cast<double*>(wsb);
+    double* sigma = reinterpret_cast<double*>(wsb + cbytes);
+    double* thr = reinterpret_cast<double*>(wsb + cbytes + round256(static_cast<size_t>(b) * 8));
+
+    rc = forward_dev(ctx, x_dev, b, n, 1, h, lh, g, lg, boundary, tflags, coeffs, nullptr, s);
+    if (rc != VW_OK) return rc;
+    const bool plain = fabs(threshold_multiplier - 1.0) < 1e-10;
+    if (noise_estimation != VW_NOISE_FIXED || !plain) {
+        StreamNoiseArgs a;
+        memset(&a, 0, sizeof(a));
+        a.details = coeffs;  // band 0 of a single-level block is the detail band
+        a.row_stride = 2 * n;
+        a.n = n;
+        a.nrows = b;
+        a.window = state->win;
+        a.w = state->window;
+        a.index0 = state->index;
+        a.estimation = noise_estimation;
+        a.want_thr = plain ? 0 : 1;
+        a.method = method;
+        a.multiplier = threshold_multiplier;
+        a.log_n = log_n < 0 ? log(static_cast<double>(n)) : log_n;
+        a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? sqrt(2.0 * a.log_n) : sqrt_2_ln_n;
+        a.level = state->level;
+        a.thr = thr;
+        a.lds_cap = 6144;
+        int64_t staged = 0;
+        if (noise_estimation != VW_NOISE_FIXED && state->window <= a.lds_cap) staged = state->window;
+        if (!plain && n <= a.lds_cap && n > staged) staged = n;
+        const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
+        if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+        hipLaunchKernelGGL(k_stream_noise, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+        VW_HIP(ctx, hipGetLastError());
+        if (noise_estimation != VW_NOISE_FIXED) state->index = (state->index + (n <= state->window ? n : state->window)) % state->window;
+    }
+    if (plain) {
+        // WaveletDenoiser.denoise(samples, method, type): FIXED has no automatic rule
+        if (method < VW_THRESHOLD_UNIVERSAL || method > VW_THRESHOLD_BAYES)
+            return set_err(ctx, VW_E_UNSUPPORTED, method == VW_THRESHOLD_FIXED
+                                                      ? "Fixed threshold method requires explicit threshold value"
+                                                      : "Unknown threshold selection method");
+        rc = denoiser_thresholds_dev(ctx, coeffs, b, n, 1, method, 0, log_n, sigma, thr, s);
+        if (rc != VW_OK) return rc;
+    } else if (method == VW_THRESHOLD_BAYES || method < VW_THRESHOLD_UNIVERSAL || method > VW_THRESHOLD_FIXED) {
+        return set_err(ctx, VW_E_UNSUPPORTED, "Unknown threshold method: %d", method);
+    }
+    if (thresholds_out_dev != nullptr)
+        VW_HIP(ctx, hipMemcpyAsync(thresholds_out_dev, thr, static_cast<size_t>(b) * 8, hipMemcpyDeviceToDevice, s));
+    rc = threshold_inverse_dev(ctx, coeffs, b, n, 1, hr, lhr, gr, lgr, boundary, tflags, soft, thr, y_dev, s);
+    if (rc == VW_OK) state->samples += n;
+    return rc;
+}
+
+extern "C" int32_t vw_streaming_denoise_batch(vw_ctx* ctx, vw_stream_state* state, const double* x, int64_t b, int64_t n,
+                                              const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
+                                              int32_t lhr, const double* gr, int32_t lgr, int32_t boundary, uint32_t flags,
+                                              int32_t method, int32_t soft, double threshold_multiplier,
+                                              int32_t noise_estimation, double log_n, double sqrt_2_ln_n, double* y,
+                                              double* thresholds_out) {
+    const uint32_t tflags = (flags & VW_FLAG_FMA) | VW_FLAG_SINGLE_LEVEL;
+    if (ctx == nullptr) return VW_E_NULL;
+    if (state == nullptr) return set_err(ctx, VW_E_NULL, "Stream state cannot be null");
+    if (b > 0 && n == 0) return set_err(ctx, VW_E_EMPTY, "Samples cannot be null or empty");
+    int rc = forward_checks(ctx, x, b, n, 1, h, lh, g, lg, boundary, tflags, y);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x, b, n, 1, hr, lhr, gr, lgr, boundary, tflags, y);
+    if (rc != VW_OK) return rc;
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // staging buffers are shared per context
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    // the streams advance together, so the whole block is staged at once
+    rc = ensure(ctx, ctx->stage_in, static_cast<size_t>(b) * n * 8);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_out, round256(static_cast<size_t>(b) * n * 8) + static_cast<size_t>(b) * 8);
+    if (rc != VW_OK) return rc;
+    double* dx = static_cast<double*>(ctx->stage_in.p);
+    double* dy = static_cast<double*>(ctx->stage_out.p);
+    double* dthr = reinterpret_cast<double*>(static_cast<char*>(ctx->stage_out.p) + round256(static_cast<size_t>(b) * n * 8));
+    VW_HIP(ctx, hipMemcpyAsync(dx, x, static_cast<size_t>(b) * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_streaming_denoise_batch_dev(ctx, state, dx, b, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, flags, method, soft,
+                                        threshold_multiplier, noise_estimation, log_n, sqrt_2_ln_n, dy,
+                                        thresholds_out != nullptr ? dthr : nullptr, nullptr, 0, ctx->stream);
+    if (rc != VW_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    VW_HIP(ctx, hipMemcpyAsync(y, dy, static_cast<size_t>(b) * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (thresholds_out != nullptr)
+        VW_HIP(ctx, hipMemcpyAsync(thresholds_out, dthr, static_cast<size_t>(b) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VW_OK;
 }
 
