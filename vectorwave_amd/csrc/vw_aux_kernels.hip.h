@@ -152,15 +152,32 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
     return v;
 }
 
-// Key source: either the LDS copy of the row (n <= cap) or global memory.
+// Key source over a row of doubles: key = bit pattern of | |v_i| - sub | (with sub = 0 the keys are |v_i|).
+// LDS only names the address space the pointer lives in: one instantiation per space keeps the loads
+// ds_read / global_load instead of flat.
+template <bool LDS>
 struct KeySrc {
-    const unsigned long long* lds;
-    const double* glob;
+    const double* v;
+    double sub;
+    __device__ __forceinline__ double raw(int64_t i) const { return v[i]; }
     __device__ __forceinline__ unsigned long long get(int64_t i) const {
-        if (lds != nullptr) return lds[i];
-        return static_cast<unsigned long long>(__double_as_longlong(glob[i])) & 0x7fffffffffffffffull;
+        return static_cast<unsigned long long>(__double_as_longlong(fabs(fabs(v[i]) - sub))) & 0x7fffffffffffffffull;
     }
 };
+
+// Copies (|.| of) a row into LDS with eight loads per lane in flight.
+template <int NT, bool ABS>
+__device__ __forceinline__ void stage_row(double* dst, const double* __restrict__ src, int64_t count) {
+    int64_t i = threadIdx.x;
+    for (; i + 7 * NT < count; i += 8 * NT) {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = src[i + j * NT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[i + j * NT] = ABS ? fabs(t[j]) : t[j];
+    }
+    for (; i < count; i += NT) dst[i] = ABS ? fabs(src[i]) : src[i];
+}
 
 // Returns the key of rank k (0-based) among n keys; all threads get the result.
 template <typename Src>
@@ -236,6 +253,163 @@ __device__ double median_select(const Src& src, int64_t n, unsigned* hist /*256*
     return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
 }
 
+
+// The same selection by ONE wavefront (workgroups of 64 lanes): no cross-wave traffic, the bin that holds
+// rank k is found with a ballot and broadcast with a shuffle.  Short rows finish several times sooner this
+// way because a pass costs no workgroup barriers and eight times as many rows are resident per CU.
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <typename Src>
+__device__ unsigned long long wave_radix_select(const Src& src, int64_t n, int64_t k, unsigned* hist /*256, 16-byte aligned*/) {
+    const int lane = threadIdx.x;
+    unsigned long long prefix = 0;
+    int64_t kk = k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+        for (int64_t base = 0; base < n; base += 64) {
+            const int64_t i = base + lane;
+            unsigned long long key = 0;
+            bool match = false;
+            if (i < n) {
+                key = src.get(i);
+                match = (key & himask) == prefix;
+            }
+            const unsigned bin = static_cast<unsigned>(key >> shift) & 0xffu;
+            // Keys of one row mostly share their leading bytes, and atomics of a wavefront on one address are
+            // served one by one: the lanes that agree with the first matching lane are counted with a ballot
+            // and added once, the rest go through the atomic unit.
+            const unsigned long long active = __ballot(match);
+            if (active != 0) {
+                const int leader = __ffsll(static_cast<long long>(active)) - 1;
+                const unsigned b0 = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(match && bin == b0);
+                if (lane == leader)
+                    atomicAdd(&hist[b0], static_cast<unsigned>(__popcll(same)));
+                else if (match && bin != b0)
+                    atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        // lane L owns bins 4L..4L+3
+        const uint4 c = reinterpret_cast<const uint4*>(hist)[lane];
+        const unsigned tot = c.x + c.y + c.z + c.w;
+        const unsigned inc = wave_inclusive_scan(tot);
+        const unsigned exc = inc - tot;
+        const bool mine = tot != 0 && static_cast<int64_t>(exc) <= kk && kk < static_cast<int64_t>(inc);
+        unsigned bin = 0, below = exc, held = c.x;
+        if (mine) {
+            if (kk >= static_cast<int64_t>(below + c.x)) {
+                below += c.x;
+                bin = 1;
+                held = c.y;
+                if (kk >= static_cast<int64_t>(below + c.y)) {
+                    below += c.y;
+                    bin = 2;
+                    held = c.z;
+                    if (kk >= static_cast<int64_t>(below + c.z)) {
+                        below += c.z;
+                        bin = 3;
+                        held = c.w;
+                    }
+                }
+            }
+        }
+        const int owner = __ffsll(static_cast<long long>(__ballot(mine))) - 1;  // exactly one lane holds rank kk
+        const unsigned sel = __shfl(static_cast<unsigned>(lane) * 4u + bin, owner, 64);
+        const unsigned nb = __shfl(below, owner, 64);
+        const unsigned in_bin = __shfl(held, owner, 64);
+        prefix |= static_cast<unsigned long long>(sel) << shift;
+        kk -= static_cast<int64_t>(nb);
+        __syncthreads();
+        if (in_bin == 1 && shift > 0) {
+            // one key left under this prefix: it is the answer, fetch it instead of descending further
+            const unsigned long long mask = ~0ull << shift;
+            unsigned long long found = ~0ull;
+            for (int64_t i = lane; i < n; i += 64) {
+                const unsigned long long key = src.get(i);
+                if ((key & mask) == prefix) found = key;
+            }
+            return wave_min_u64(found);
+        }
+    }
+    return prefix;
+}
+
+template <typename Src>
+__device__ double wave_median_select(const Src& src, int64_t n, unsigned* hist) {
+    const int lane = threadIdx.x;
+    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+    const unsigned long long v1 = wave_radix_select(src, n, k1, hist);
+    if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
+    unsigned long long le = 0, above = ~0ull;
+    for (int64_t i = lane; i < n; i += 64) {
+        const unsigned long long key = src.get(i);
+        if (key <= v1)
+            ++le;
+        else if (key < above)
+            above = key;
+    }
+    le = wave_sum_u64(le);
+    above = wave_min_u64(above);
+    const unsigned long long v2 = (static_cast<int64_t>(le) >= k1 + 2) ? v1 : above;
+    return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
+}
+
+// LDS scratch of the selection helpers for a workgroup of NT lanes (64: one wavefront; kThreads: four)
+template <int NT>
+struct SelLds {
+    __align__(16) unsigned hist[256];
+    unsigned wsum[4];
+    unsigned long long bcast[2];
+    unsigned long long red[kThreads];
+};
+template <>
+struct SelLds<64> {
+    __align__(16) unsigned hist[256];
+};
+
+template <int NT, typename Src>
+__device__ __forceinline__ double median_nt(const Src& src, int64_t n, SelLds<NT>& l) {
+    if constexpr (NT == 64)
+        return wave_median_select(src, n, l.hist);
+    else
+        return median_select(src, n, l.hist, l.wsum, l.bcast, l.red);
+}
+
+// sum of one value per lane over the workgroup; every lane gets it
+template <int NT>
+__device__ __forceinline__ unsigned long long sum_nt(unsigned long long v, SelLds<NT>& l) {
+    if constexpr (NT == 64) {
+        return wave_sum_u64(v);
+    } else {
+        const int tid = threadIdx.x;
+        l.red[tid] = v;
+        __syncthreads();
+        for (int s = kThreads / 2; s > 0; s >>= 1) {
+            if (tid < s) l.red[tid] += l.red[tid + s];
+            __syncthreads();
+        }
+        const unsigned long long r = l.red[0];
+        __syncthreads();
+        return r;
+    }
+}
+
 struct MedianArgs {
     const double* d1;      // band d_1 of row r at d1 + r*row_stride
     int64_t row_stride;
@@ -246,29 +420,29 @@ struct MedianArgs {
     int32_t lds_cap;       // rows up to this length are copied into LDS
 };
 
-__global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianArgs a) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_universal_threshold(const MedianArgs a) {
     extern __shared__ double2 vw_smem[];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned long long bcast[2];
-    __shared__ unsigned long long red[kThreads];
-    const int tid = threadIdx.x;
+    __shared__ SelLds<NT> sel;
     const int64_t row = blockIdx.x;
     const int64_t n = a.n;
     const double* __restrict__ d = a.d1 + row * a.row_stride;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(vw_smem);
-
-    KeySrc src;
-    src.glob = d;
-    src.lds = nullptr;
+    double* stage = reinterpret_cast<double*>(vw_smem);
+    double median;
     if (n <= a.lds_cap) {
-        for (int64_t i = tid; i < n; i += kThreads)
-            keys[i] = static_cast<unsigned long long>(__double_as_longlong(d[i])) & 0x7fffffffffffffffull;
-        src.lds = keys;
+        stage_row<NT, true>(stage, d, n);
         __syncthreads();
+        KeySrc<true> src;
+        src.v = stage;
+        src.sub = 0.0;
+        median = median_nt<NT>(src, n, sel);
+    } else {
+        KeySrc<false> src;
+        src.v = d;
+        src.sub = 0.0;
+        median = median_nt<NT>(src, n, sel);
     }
-    const double median = median_select(src, n, hist, wsum, bcast, red);
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const double sigma = median / 0.6745;
         a.thr_out[row] = sigma * a.sqrt_2_ln_n;
     }
@@ -285,17 +459,6 @@ __global__ void __launch_bounds__(kThreads) k_universal_threshold(const MedianAr
 // order.  With a threshold multiplier the block's threshold comes from that level (or, when there is none
 // yet, from the MAD of the block's own |details|).
 
-// key = bit pattern of | |v_i| - sub |: with sub = 0 the keys are |v_i| themselves
-struct AbsDevSrc {
-    const double* lds;
-    const double* glob;
-    double sub;
-    __device__ __forceinline__ unsigned long long get(int64_t i) const {
-        const double v = lds != nullptr ? lds[i] : glob[i];
-        return static_cast<unsigned long long>(__double_as_longlong(fabs(fabs(v) - sub))) & 0x7fffffffffffffffull;
-    }
-};
-
 struct StreamNoiseArgs {
     const double* details;  // band d_1 of stream r at details + r*row_stride
     int64_t row_stride;
@@ -304,7 +467,9 @@ struct StreamNoiseArgs {
     double* window;         // [nrows][w]
     int64_t w;
     int64_t index0;         // ring position before this block
-    int32_t estimation;     // 0 MAD, 1 STD, 2 FIXED (ring and level untouched)
+    int32_t estimation;     // 0 MAD, 1 STD, 2 FIXED: selects the estimator and the sigma rule of the threshold
+    int32_t do_update;      // 1: the block's picks enter the ring
+    int32_t do_level;       // 1: the level is re-estimated here (MAD; STD when no other kernel does it)
     int32_t want_thr;       // 1: write thr = base threshold * multiplier
     int32_t method;         // 0 UNIVERSAL, 1 SURE (0.8 * universal), 2 MINIMAX, 4 FIXED (sigma itself)
     double multiplier;
@@ -316,12 +481,11 @@ struct StreamNoiseArgs {
 };
 
 // MAD of |v_0..n-1| with the reference's guards: 0 when no entry is finite or every finite entry is zero
-__device__ double stream_mad(AbsDevSrc& src, int64_t n, unsigned* hist, unsigned* wsum, unsigned long long* bcast,
-                             unsigned long long* red) {
-    const int tid = threadIdx.x;
+template <int NT, typename Src>
+__device__ double stream_mad(Src& src, int64_t n, SelLds<NT>& sel) {
     int fin = 0, nz = 0;
-    for (int64_t i = tid; i < n; i += kThreads) {
-        const double v = src.lds != nullptr ? src.lds[i] : src.glob[i];
+    for (int64_t i = threadIdx.x; i < n; i += NT) {
+        const double v = src.raw(i);
         if (finite_f64(v)) {
             fin = 1;
             if (v != 0.0) nz = 1;
@@ -331,18 +495,88 @@ __device__ double stream_mad(AbsDevSrc& src, int64_t n, unsigned* hist, unsigned
     const int any_nz = __syncthreads_or(nz);
     if (!any_fin || !any_nz) return 0.0;
     src.sub = 0.0;
-    const double med = median_select(src, n, hist, wsum, bcast, red);
+    const double med = median_nt<NT>(src, n, sel);
     src.sub = med;
-    return median_select(src, n, hist, wsum, bcast, red);
+    return median_nt<NT>(src, n, sel);
 }
 
-__global__ void __launch_bounds__(kThreads) k_stream_noise(const StreamNoiseArgs a) {
+// Sample standard deviation of v_0..w-1, summed in index order by the calling lane.  The loads of a group of
+// 16 are issued together so that the adder chain, not the memory latency, sets the pace.
+__device__ double sequential_std(const double* v, int64_t w) {
+#pragma clang fp contract(off)
+    double sum = 0.0;
+    int64_t i = 0;
+    for (; i + 16 <= w; i += 16) {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = v[i + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += t[j];
+    }
+    for (; i < w; ++i) sum += v[i];
+    const double mean = sum / static_cast<double>(w);
+    double ssd = 0.0;
+    i = 0;
+    for (; i + 16 <= w; i += 16) {
+        double t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double diff = v[i + j] - mean;
+            t[j] = diff * diff;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ssd += t[j];
+    }
+    for (; i < w; ++i) {
+        const double diff = v[i] - mean;
+        ssd += diff * diff;
+    }
+    return sqrt(ssd / static_cast<double>(w - 1));
+}
+
+// noise level of a ring: MAD / 0.6745 (estimation 0) or the standard deviation (1); every lane gets it
+template <int NT, typename Src>
+__device__ double ring_level(Src& src, int64_t w, int estimation, SelLds<NT>& sel, double* bc) {
+    if (estimation == 0) return stream_mad<NT>(src, w, sel) / 0.6745;
+    unsigned long long fin = 0;
+    for (int64_t i = threadIdx.x; i < w; i += NT) fin += finite_f64(src.raw(i)) ? 1 : 0;
+    fin = sum_nt<NT>(fin, sel);
+    if (threadIdx.x == 0) *bc = fin >= 2 ? sequential_std(src.v, w) : 0.0;  // fewer than two finite entries: 0
+    __syncthreads();
+    const double r = *bc;
+    __syncthreads();
+    return r;
+}
+
+// index of the k-th |detail| a block of n > w samples contributes to a ring of w: strata 0..extra-1 give
+// per+1 picks each, the rest per; picks are evenly spaced inside their stratum
+__device__ __forceinline__ unsigned stratified_pick(unsigned k, unsigned n, unsigned w) {
+    const unsigned strata = w < 10u ? w : 10u;
+    const unsigned per = w / strata, extra = w % strata, size = n / strata;
+    unsigned s, i;
+    if (k < extra * (per + 1u)) {
+        s = k / (per + 1u);
+        i = k - s * (per + 1u);
+    } else {
+        const unsigned kk = k - extra * (per + 1u);
+        s = extra + kk / per;
+        i = kk - (kk / per) * per;
+    }
+    const unsigned take = per + (s < extra ? 1u : 0u);
+    const unsigned start = s * size;
+    const unsigned end = (s == strata - 1u) ? n : (s + 1u) * size;
+    const unsigned len = end - start;
+    const unsigned step = len / take > 1u ? len / take : 1u;
+    return start + (i * step) % len;
+}
+
+// NT = 64: one wavefront per stream, for rings and blocks short enough that a lane's share of a selection
+// pass is a few dozen keys; NT = kThreads otherwise.  n and w are below 2^31 (checked by the host).
+template <int NT>
+__global__ void __launch_bounds__(NT) k_stream_noise(const StreamNoiseArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ double2 vw_smem[];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned wsum[4];
-    __shared__ unsigned long long bcast[2];
-    __shared__ unsigned long long red[kThreads];
+    __shared__ SelLds<NT> sel;
     __shared__ double bc;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
@@ -350,74 +584,46 @@ __global__ void __launch_bounds__(kThreads) k_stream_noise(const StreamNoiseArgs
     const double* __restrict__ d = a.details + row * a.row_stride;
     double* win = a.window + row * w;
     double* stage = reinterpret_cast<double*>(vw_smem);
+    const bool ring_in_lds = a.do_level && w <= a.lds_cap;
     double lvl;
 
-    if (a.estimation != 2) {
-        const int64_t m = n <= w ? n : w;
-        const int64_t strata = w < 10 ? w : 10;
-        const int64_t per = w / strata, extra = w % strata, size = n / strata;
-        for (int64_t k = tid; k < m; k += kThreads) {
-            int64_t src_i = k;
-            if (n > w) {
-                // k-th pick: strata 0..extra-1 give per+1 picks each, the rest give per
-                int64_t s, i;
-                if (k < extra * (per + 1)) {
-                    s = k / (per + 1);
-                    i = k - s * (per + 1);
-                } else {
-                    const int64_t kk = k - extra * (per + 1);
-                    s = extra + kk / per;
-                    i = kk - (kk / per) * per;
-                }
-                const int64_t take = per + (s < extra ? 1 : 0);
-                const int64_t start = s * size;
-                const int64_t end = (s == strata - 1) ? n : (s + 1) * size;
-                const int64_t len = end - start;
-                const int64_t step = len / take > 1 ? len / take : 1;
-                src_i = start + (i * step) % len;
+    if (a.do_update) {
+        // the old ring goes to LDS while the block's picks are fetched; the picks then patch both copies
+        if (ring_in_lds) stage_row<NT, false>(stage, win, w);
+        const unsigned m = static_cast<unsigned>(n <= w ? n : w);
+        const unsigned un = static_cast<unsigned>(n), uw = static_cast<unsigned>(w), i0 = static_cast<unsigned>(a.index0);
+        if (ring_in_lds) __syncthreads();
+        for (unsigned k0 = 0; k0 < m; k0 += 4 * NT) {
+            double t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned k = k0 + j * NT + tid;
+                if (k < m) t[j] = fabs(d[un > uw ? stratified_pick(k, un, uw) : k]);
             }
-            win[(a.index0 + k) % w] = fabs(d[src_i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned k = k0 + j * NT + tid;
+                if (k < m) {
+                    unsigned slot = i0 + k;  // both below w
+                    if (slot >= uw) slot -= uw;
+                    win[slot] = t[j];
+                    if (ring_in_lds) stage[slot] = t[j];
+                }
+            }
         }
+        if (!a.do_level) return;  // the level comes from another kernel
         __threadfence_block();
         __syncthreads();
-        AbsDevSrc src;
-        src.glob = win;
-        src.lds = nullptr;
-        src.sub = 0.0;
-        if (w <= a.lds_cap) {
-            for (int64_t i = tid; i < w; i += kThreads) stage[i] = win[i];
-            src.lds = stage;
-            __syncthreads();
-        }
-        if (a.estimation == 0) {
-            lvl = stream_mad(src, w, hist, wsum, bcast, red) / 0.6745;
+        if (ring_in_lds) {
+            KeySrc<true> src;
+            src.v = stage;
+            src.sub = 0.0;
+            lvl = ring_level<NT>(src, w, a.estimation, sel, &bc);
         } else {
-            unsigned long long fin = 0;
-            for (int64_t i = tid; i < w; i += kThreads) fin += finite_f64(src.lds != nullptr ? src.lds[i] : src.glob[i]) ? 1 : 0;
-            red[tid] = fin;
-            __syncthreads();
-            for (int s = kThreads / 2; s > 0; s >>= 1) {
-                if (tid < s) red[tid] += red[tid + s];
-                __syncthreads();
-            }
-            if (tid == 0) {
-                double r = 0.0;
-                if (red[0] >= 2) {  // fewer than two finite entries: no standard deviation
-                    const double* v = src.lds != nullptr ? src.lds : src.glob;
-                    double sum = 0.0;
-                    for (int64_t i = 0; i < w; ++i) sum += v[i];
-                    const double mean = sum / static_cast<double>(w);
-                    double ssd = 0.0;
-                    for (int64_t i = 0; i < w; ++i) {
-                        const double diff = v[i] - mean;
-                        ssd += diff * diff;
-                    }
-                    r = sqrt(ssd / static_cast<double>(w - 1));
-                }
-                bc = r;
-            }
-            __syncthreads();
-            lvl = bc;
+            KeySrc<false> src;
+            src.v = win;
+            src.sub = 0.0;
+            lvl = ring_level<NT>(src, w, a.estimation, sel, &bc);
         }
         if (tid == 0) a.level[row] = lvl;
     } else {
@@ -428,17 +634,20 @@ __global__ void __launch_bounds__(kThreads) k_stream_noise(const StreamNoiseArgs
     double sigma = lvl;
     if (sigma <= 0.0 || a.estimation == 2) {
         __syncthreads();  // the ring's LDS copy is dead from here on
-        AbsDevSrc src;
-        src.glob = d;
-        src.lds = nullptr;
-        src.sub = 0.0;
         if (n <= a.lds_cap) {
-            for (int64_t i = tid; i < n; i += kThreads) stage[i] = fabs(d[i]);
-            src.lds = stage;
+            stage_row<NT, true>(stage, d, n);
             __syncthreads();
+            KeySrc<true> src;
+            src.v = stage;
+            src.sub = 0.0;
+            sigma = stream_mad<NT>(src, n, sel) / 0.6745;
+        } else {
+            // signed details: the guards see the same finite / non-zero pattern and the keys take |v|
+            KeySrc<false> src;
+            src.v = d;
+            src.sub = 0.0;
+            sigma = stream_mad<NT>(src, n, sel) / 0.6745;
         }
-        // a global source holds signed details: the guards see the same finite / non-zero pattern and the keys take |v|
-        sigma = stream_mad(src, n, hist, wsum, bcast, red) / 0.6745;
     }
     if (tid == 0) {
         double base;
@@ -608,66 +817,119 @@ __global__ void __launch_bounds__(kThreads) k_denoiser_thresholds(const Denoiser
 }
 
 
-// BAYES thresholds, 64 bands per single-wave workgroup.  The mean and the variance must be running sums
-// in index order (that is what the Java loops round to), so a band is one dependent chain of adds; the
-// parallelism is across bands: every lane owns one (row, level) band and adds its elements in order,
-// while the wave loads the 64 bands' next 64 elements with coalesced 512-byte reads and transposes
-// them through LDS (row stride 65 doubles: conflict-free both ways).
-__global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) {
-    __shared__ double tile[64 * 65];
+// Mean and sum of squared deviations of 16 rows at once, one row per lane 0..15 of a single-wave workgroup.
+// Both must be running sums in index order (that is what the Java loops round to), so a row is one dependent
+// chain of adds; the parallelism is across rows.  The wave fetches the 16 rows' next 256 elements with 64
+// coalesced 512-byte loads that stay in flight while the lanes add the previous 256 out of LDS (row stride
+// 257 doubles: conflict-free for the 16 adding lanes).  A lane that walked one chain alone per wave would
+// keep the FP64 pipe busy for a full wavefront per add, and a wave that waited for every load before adding
+// would spend its time on memory latency.
+//   my_ptr: address of this lane's row (lanes >= nq hold none); mean = (sum v_i) / n; ssd = sum (v_i - mean)^2;
+//   nfinite = finite entries of the row (COUNT only).
+constexpr int kChainRows = 16;
+constexpr int kChainCols = 256;
+constexpr int kChainStride = kChainCols + 1;
+
+template <bool COUNT>
+__device__ __forceinline__ void lane_chains(unsigned long long my_ptr, bool have, int nq, int64_t n,
+                                            double* tile /*kChainRows * kChainStride*/, double& mean, double& ssd,
+                                            unsigned& nfinite) {
+#pragma clang fp contract(off)
     const int lane = threadIdx.x;
-    const int64_t nbands = a.nrows * a.levels;
-    const int64_t band0 = static_cast<int64_t>(blockIdx.x) * 64;
-    const int64_t n = a.n;
-    const int64_t mine = band0 + lane;
-    const bool have = mine < nbands;
-    const int64_t my_row = have ? mine / a.levels : 0;
-    const int my_level = have ? static_cast<int>(mine - my_row * a.levels) + 1 : 1;
-    const unsigned long long my_ptr = reinterpret_cast<unsigned long long>(
-        a.coeffs + my_row * a.row_stride + static_cast<int64_t>(my_level - 1) * a.band_stride);
-    const int nq = static_cast<int>((nbands - band0) < 64 ? (nbands - band0) : 64);
-    double mean = 0.0, variance = 0.0;
+    const double* rowp[kChainRows];
+#pragma unroll
+    for (int r = 0; r < kChainRows; ++r) {
+        const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(my_ptr & 0xffffffffu), r);
+        const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(my_ptr >> 32), r);
+        rowp[r] = reinterpret_cast<const double*>((static_cast<unsigned long long>(hi) << 32) | lo);
+    }
+    mean = 0.0;
+    ssd = 0.0;
+    nfinite = 0;
+    double v[kChainRows * 4];
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int r = 0; r < kChainRows; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t i = base + c * 64 + lane;
+                v[r * 4 + c] = (r < nq && i < n) ? rowp[r][i] : 0.0;
+            }
+    };
     for (int pass = 0; pass < 2; ++pass) {
         double acc = 0.0;
-        for (int64_t base = 0; base < n; base += 64) {
-            const int cnt = static_cast<int>((n - base) < 64 ? (n - base) : 64);
-            // wave-uniform loop over the 64 bands: lane = element index within the chunk; band q's base
-            // address lives in lane q
-            // 16 loads in flight at a time, then 16 LDS writes
+        fetch(0);
+        for (int64_t base = 0; base < n; base += kChainCols) {
+            const int cnt = static_cast<int>((n - base) < kChainCols ? (n - base) : kChainCols);
 #pragma unroll
-            for (int q0 = 0; q0 < 64; q0 += 16) {
-                double v[16];
+            for (int r = 0; r < kChainRows; ++r)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int q = q0 + u;
-                    const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(my_ptr & 0xffffffffu), q);
-                    const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(my_ptr >> 32), q);
-                    const double* __restrict__ c =
-                        reinterpret_cast<const double*>((static_cast<unsigned long long>(hi) << 32) | lo);
-                    v[u] = (q < nq && lane < cnt) ? c[base + lane] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) tile[(q0 + u) * 65 + lane] = v[u];
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // one wave: no barrier needed
+                for (int c = 0; c < 4; ++c) tile[r * kChainStride + c * 64 + lane] = v[r * 4 + c];
+            if (base + kChainCols < n) fetch(base + kChainCols);  // in flight while the lanes add
+            __syncthreads();
             if (have) {
+                const double* t = tile + lane * kChainStride;
+                int i = 0;
                 if (pass == 0) {
-                    for (int i = 0; i < cnt; ++i) acc += tile[lane * 65 + i];
+                    for (; i + 16 <= cnt; i += 16) {
+                        double u[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) u[j] = t[i + j];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            acc += u[j];
+                            if (COUNT) nfinite += finite_f64(u[j]) ? 1u : 0u;
+                        }
+                    }
+                    for (; i < cnt; ++i) {
+                        acc += t[i];
+                        if (COUNT) nfinite += finite_f64(t[i]) ? 1u : 0u;
+                    }
                 } else {
-                    for (int i = 0; i < cnt; ++i) {
-                        const double diff = tile[lane * 65 + i] - mean;
+                    for (; i + 16 <= cnt; i += 16) {
+                        double u[16];
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const double diff = t[i + j] - mean;
+                            u[j] = diff * diff;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc += u[j];
+                    }
+                    for (; i < cnt; ++i) {
+                        const double diff = t[i] - mean;
                         acc += diff * diff;
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
         }
         if (pass == 0)
             mean = acc / static_cast<double>(n);
         else
-            variance = acc / static_cast<double>(n);
+            ssd = acc;
     }
+}
+
+// BAYES thresholds, 16 (row, level) bands per single-wave workgroup
+__global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) {
+    __shared__ double tile[kChainRows * kChainStride];
+    const int lane = threadIdx.x;
+    const int64_t nbands = a.nrows * a.levels;
+    const int64_t band0 = static_cast<int64_t>(blockIdx.x) * kChainRows;
+    const int64_t n = a.n;
+    const int64_t mine = band0 + lane;
+    const bool have = lane < kChainRows && mine < nbands;
+    const int64_t my_row = have ? mine / a.levels : 0;
+    const int my_level = have ? static_cast<int>(mine - my_row * a.levels) + 1 : 1;
+    const unsigned long long my_ptr = reinterpret_cast<unsigned long long>(
+        a.coeffs + my_row * a.row_stride + static_cast<int64_t>(my_level - 1) * a.band_stride);
+    const int nq = static_cast<int>((nbands - band0) < kChainRows ? (nbands - band0) : kChainRows);
+    double mean, ssd;
+    unsigned unused;
+    lane_chains<false>(my_ptr, have, nq, n, tile, mean, ssd, unused);
     if (have) {
+        const double variance = ssd / static_cast<double>(n);
         double sigma = a.sigma[my_row];
         if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (my_level - 1)));
         const double sigma2 = sigma * sigma;
@@ -676,6 +938,22 @@ __global__ void __launch_bounds__(64) k_denoiser_bayes(const DenoiserThrArgs a) 
         const double sx = sqrt(sx2 + 1e-10);
         a.thr[my_row * a.levels + (my_level - 1)] = sigma2 / sx;
     }
+}
+
+// Streaming denoiser, STD estimator: level = sample standard deviation of each stream's ring, 16 streams per
+// single-wave workgroup; 0 for a ring with fewer than two finite entries.
+__global__ void __launch_bounds__(64) k_stream_std(const StreamNoiseArgs a) {
+    __shared__ double tile[kChainRows * kChainStride];
+    const int lane = threadIdx.x;
+    const int64_t s0 = static_cast<int64_t>(blockIdx.x) * kChainRows;
+    const int64_t mine = s0 + lane;
+    const bool have = lane < kChainRows && mine < a.nrows;
+    const unsigned long long my_ptr = reinterpret_cast<unsigned long long>(a.window + (have ? mine : 0) * a.w);
+    const int nq = static_cast<int>((a.nrows - s0) < kChainRows ? (a.nrows - s0) : kChainRows);
+    double mean, ssd;
+    unsigned nfinite;
+    lane_chains<true>(my_ptr, have, nq, a.w, tile, mean, ssd, nfinite);
+    if (have) a.level[mine] = nfinite >= 2 ? sqrt(ssd / static_cast<double>(a.w - 1)) : 0.0;
 }
 
 // ---------------------------------------------------------------------------

@@ -1024,6 +1024,16 @@ extern "C" int32_t vw_threshold(vw_ctx* ctx, const double* in, int64_t count, do
 
 static double host_sqrt_2_ln_n(int64_t n) { return sqrt(2 * log(static_cast<double>(n))); }
 
+// rows of up to kWaveSelectMax samples go one wavefront per row, longer rows one 256-lane workgroup per row
+static constexpr int64_t kWaveSelectMax = 2048;
+
+static void launch_universal_threshold(const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
+    if (n <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
+        hipLaunchKernelGGL(k_universal_threshold<64>, dim3(static_cast<unsigned>(b)), dim3(64), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_universal_threshold<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+}
+
 static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels,
                                    double sqrt_2_ln_n, double* thr, hipStream_t s) {
     MedianArgs a;
@@ -1037,7 +1047,7 @@ static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     a.lds_cap = 4096;
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
     if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-    hipLaunchKernelGGL(k_universal_threshold, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+    launch_universal_threshold(a, b, n, lds, s);
     VW_HIP(ctx, hipGetLastError());
     return VW_OK;
 }
@@ -1085,7 +1095,7 @@ extern "C" int32_t vw_swt_universal_threshold_batch(vw_ctx* ctx, const double* c
     a.thr_out = t;
     a.lds_cap = 4096;
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
-    hipLaunchKernelGGL(k_universal_threshold, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, ctx->stream, a);
+    launch_universal_threshold(a, b, n, lds, ctx->stream);
     VW_HIP(ctx, hipGetLastError());
     VW_HIP(ctx, hipMemcpyAsync(thresholds, t, static_cast<size_t>(b) * 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1253,7 +1263,7 @@ static int denoiser_thresholds_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     const int64_t nblocks = b * levels;
     if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
     if (method == VW_THRESHOLD_BAYES)
-        hipLaunchKernelGGL(k_denoiser_bayes, dim3(static_cast<unsigned>((nblocks + 63) / 64)), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_denoiser_bayes, dim3(static_cast<unsigned>((nblocks + kChainRows - 1) / kChainRows)), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_denoiser_thresholds, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
     VW_HIP(ctx, hipGetLastError());
@@ -1531,6 +1541,7 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
     if (noise_estimation < VW_NOISE_MAD || noise_estimation > VW_NOISE_FIXED)
         return set_err(ctx, VW_E_UNSUPPORTED, "Unknown noise estimation method");
     if (!(threshold_multiplier > 0)) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold multiplier must be positive");
+    if (n > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "blocks of more than 2^31-1 samples are not supported");
     if (state->device != ctx->device) return set_err(ctx, VW_E_UNSUPPORTED, "stream state belongs to another device");
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
@@ -1564,7 +1575,6 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
         a.w = state->window;
         a.index0 = state->index;
         a.estimation = noise_estimation;
-        a.want_thr = plain ? 0 : 1;
         a.method = method;
         a.multiplier = threshold_multiplier;
         a.log_n = log_n < 0 ? log(static_cast<double>(n)) : log_n;
@@ -1572,12 +1582,39 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
         a.level = state->level;
         a.thr = thr;
         a.lds_cap = 6144;
-        int64_t staged = 0;
-        if (noise_estimation != VW_NOISE_FIXED && state->window <= a.lds_cap) staged = state->window;
-        if (!plain && n <= a.lds_cap && n > staged) staged = n;
-        const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
         if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-        hipLaunchKernelGGL(k_stream_noise, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+        // one launch updates the ring, estimates the level and (with a multiplier) derives the threshold; the STD
+        // estimator runs between two such launches in a kernel of its own that walks 64 rings per wavefront
+        auto launch = [&](int do_update, int do_level, int want_thr) {
+            a.do_update = do_update;
+            a.do_level = do_level;
+            a.want_thr = want_thr;
+            int64_t staged = 0, longest = 0;
+            if (do_update && n < state->window) longest = n;
+            if (do_update && n >= state->window) longest = state->window;
+            if (do_level) {
+                longest = state->window;
+                if (state->window <= a.lds_cap) staged = state->window;
+            }
+            if (want_thr) {
+                if (n > longest) longest = n;
+                if (n <= a.lds_cap && n > staged) staged = n;
+            }
+            const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
+            if (longest <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
+                hipLaunchKernelGGL(k_stream_noise<64>, dim3(static_cast<unsigned>(b)), dim3(64), lds, s, a);
+            else
+                hipLaunchKernelGGL(k_stream_noise<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+        };
+        if (noise_estimation == VW_NOISE_STD && getenv("VW_NO_STD_CHAINS") == nullptr) {
+            launch(1, 0, 0);
+            hipLaunchKernelGGL(k_stream_std, dim3(static_cast<unsigned>((b + kChainRows - 1) / kChainRows)), dim3(64), 0, s, a);
+            if (!plain) launch(0, 0, 1);
+        } else if (noise_estimation != VW_NOISE_FIXED) {
+            launch(1, 1, plain ? 0 : 1);
+        } else {
+            launch(0, 0, 1);
+        }
         VW_HIP(ctx, hipGetLastError());
         if (noise_estimation != VW_NOISE_FIXED) state->index = (state->index + (n <= state->window ? n : state->window)) % state->window;
     }
