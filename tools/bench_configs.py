@@ -116,16 +116,19 @@ def main():
         w = get_wavelet("db4")
         dp = C.POINTER(C.c_double)
         taps = [np.ascontiguousarray(t, dtype=np.float64) for t in (w.dec_lo, w.dec_hi, w.rec_lo, w.rec_hi)]
-        x = dev_signals(rows, n, seed=7, noise=0.3)
+        xs = [dev_signals(rows, n, seed=7 + q, noise=0.3) for q in range(8)]  # a new block per call, as a stream delivers
+        x = xs[0]
         y = torch.empty_like(x)
         sp = C.c_void_p(stream.cuda_stream)
+        calls = [0]
         for est, mult, label in ((0, 1.0, "MAD"), (0, 1.5, "MAD x1.5"), (1, 1.5, "STD x1.5"), (2, 1.0, "FIXED")):
             state = C.c_void_p()
             assert ctx.lib.vw_stream_state_create(ctx.handle, rows, window, C.byref(state)) == 0
 
             def run():
+                calls[0] += 1
                 st = ctx.lib.vw_streaming_denoise_batch_dev(
-                    ctx.handle, state, C.c_void_p(x.data_ptr()), rows, n, taps[0].ctypes.data_as(dp), taps[0].size,
+                    ctx.handle, state, C.c_void_p(xs[calls[0] % 8].data_ptr()), rows, n, taps[0].ctypes.data_as(dp), taps[0].size,
                     taps[1].ctypes.data_as(dp), taps[1].size, taps[2].ctypes.data_as(dp), taps[2].size,
                     taps[3].ctypes.data_as(dp), taps[3].size, 0, 0, 0, 1, mult, est, -1.0, -1.0, C.c_void_p(y.data_ptr()),
                     None, None, 0, sp)

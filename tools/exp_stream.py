@@ -21,7 +21,8 @@ dp = C.POINTER(C.c_double)
 w = get_wavelet("db4")
 taps = [np.ascontiguousarray(t, dtype=np.float64) for t in (w.dec_lo, w.dec_hi, w.rec_lo, w.rec_hi)]
 rows, n = 8192, 480
-x = dev_signals(rows, n, seed=7, noise=0.3)
+xs = [dev_signals(rows, n, seed=7 + q, noise=0.3) for q in range(8)]  # a new block per call: a ring of repeats is degenerate
+x = xs[0]
 y = torch.empty_like(x)
 for window in (64, 256, 1024, 2048):
     for est, mult in ((0, 1.0), (1, 1.0)):
@@ -33,7 +34,7 @@ for window in (64, 256, 1024, 2048):
                 torch.cuda.synchronize()
                 e0.record(stream)
             st = ctx.lib.vw_streaming_denoise_batch_dev(
-                ctx.handle, state, C.c_void_p(x.data_ptr()), rows, n, taps[0].ctypes.data_as(dp), taps[0].size,
+                ctx.handle, state, C.c_void_p(xs[it % 8].data_ptr()), rows, n, taps[0].ctypes.data_as(dp), taps[0].size,
                 taps[1].ctypes.data_as(dp), taps[1].size, taps[2].ctypes.data_as(dp), taps[2].size,
                 taps[3].ctypes.data_as(dp), taps[3].size, 0, 0, 0, 1, mult, est, -1.0, -1.0, C.c_void_p(y.data_ptr()),
                 None, None, 0, sp)

@@ -410,6 +410,140 @@ __device__ __forceinline__ unsigned long long sum_nt(unsigned long long v, SelLd
     }
 }
 
+// ---------------------------------------------------------------------------
+// selection over a row held in registers (one wavefront per row, rows of up to 64 * KPL samples)
+// ---------------------------------------------------------------------------
+//
+// Lane L holds the non-negative doubles v[j] = row[j * 64 + L]; their bit patterns are the keys.  Entries past
+// the end of the row hold the all-ones pattern, which is above every |double| and every threshold used here.
+// The rank-k key is found by descending its bits two at a time: three thresholds split the current range in
+// four, every key is compared with them, and ballots count the keys below each.  No LDS, no atomics (a
+// histogram in LDS serialises the many lanes that hit one bin, and all the wavefronts of a CU share that
+// unit), no barriers; bits that all keys share are skipped, and the descent stops as soon as one key is
+// left in the range.
+
+__device__ __forceinline__ double reg_pad() { return __longlong_as_double(-1ll); }
+
+__device__ __forceinline__ unsigned wave_and_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v &= __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <int KPL>
+__device__ __forceinline__ unsigned count_below(const double (&v)[KPL], unsigned long long t) {
+    unsigned c = 0;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+        c += static_cast<unsigned>(__popcll(__ballot(static_cast<unsigned long long>(__double_as_longlong(v[j])) < t)));
+    return c;
+}
+
+template <int KPL>
+__device__ __forceinline__ unsigned long long reg_select(const double (&v)[KPL], int64_t n, int64_t k) {
+    unsigned ah = ~0u, al = ~0u, oh = 0u, ol = 0u;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned hi = static_cast<unsigned>(__double2hiint(v[j])), lo = static_cast<unsigned>(__double2loint(v[j]));
+        const bool valid = static_cast<int>(hi) >= 0;  // the padding pattern has bit 63 set, no key has
+        ah &= hi;  // padding is all ones: neutral here
+        al &= lo;
+        oh |= valid ? hi : 0u;
+        ol |= valid ? lo : 0u;
+    }
+    const unsigned long long all_and = (static_cast<unsigned long long>(wave_and_u32(ah)) << 32) | wave_and_u32(al);
+    const unsigned long long all_or = (static_cast<unsigned long long>(wave_or_u32(oh)) << 32) | wave_or_u32(ol);
+    const unsigned long long diff = all_and ^ all_or;
+    if (diff == 0) return all_and;  // every key is the same
+    int pos = 64 - __clzll(static_cast<long long>(diff));  // bits [0, pos) are undecided
+    unsigned long long prefix = pos >= 64 ? 0ull : (all_and & (~0ull << pos));
+    unsigned below = 0;                        // keys under the current range
+    unsigned in_range = static_cast<unsigned>(n);
+    const unsigned kk = static_cast<unsigned>(k);
+#pragma unroll 1
+    while (pos > 0 && in_range > 1) {
+        const int step = pos >= 2 ? 2 : 1;
+        pos -= step;
+        const unsigned c1 = count_below<KPL>(v, prefix | (1ull << pos));
+        unsigned c2 = below + in_range, c3 = below + in_range;
+        if (step == 2) {
+            c2 = count_below<KPL>(v, prefix | (2ull << pos));
+            c3 = count_below<KPL>(v, prefix | (3ull << pos));
+        }
+        const unsigned end = below + in_range;
+        unsigned q, lo_c, hi_c;
+        if (kk < c1) {
+            q = 0; lo_c = below; hi_c = c1;
+        } else if (kk < c2) {
+            q = 1; lo_c = c1; hi_c = c2;
+        } else if (kk < c3) {
+            q = 2; lo_c = c2; hi_c = c3;
+        } else {
+            q = 3; lo_c = c3; hi_c = end;
+        }
+        prefix |= static_cast<unsigned long long>(q) << pos;
+        below = lo_c;
+        in_range = hi_c - lo_c;
+    }
+    if (pos == 0) return prefix;
+    // one key left in [prefix, prefix + 2^pos): it is the answer
+    const unsigned long long mask = ~0ull << pos;
+    unsigned long long found = ~0ull;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
+        if ((key & mask) == prefix) found = key;
+    }
+    return wave_min_u64(found);
+}
+
+// median the way the reference takes it from a sorted copy (mean of the two middle elements for even n)
+template <int KPL>
+__device__ __forceinline__ double reg_median(const double (&v)[KPL], int64_t n) {
+    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+    const unsigned long long v1 = reg_select<KPL>(v, n, k1);
+    if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
+    unsigned long long le = 0, above = ~0ull;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
+        if (key <= v1)
+            ++le;
+        else if (key < above)
+            above = key;
+    }
+    le = wave_sum_u64(le);
+    above = wave_min_u64(above);
+    const unsigned long long v2 = (static_cast<int64_t>(le) >= k1 + 2) ? v1 : above;
+    return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
+}
+
+// MAD with the streaming denoiser's guards (0 when no entry is finite or every finite entry is zero);
+// v is overwritten with the absolute deviations
+template <int KPL>
+__device__ __forceinline__ double reg_mad(double (&v)[KPL], int64_t n) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    bool fin = false, nz = false;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j)
+        if (static_cast<int64_t>(j) * 64 + lane < n && finite_f64(v[j])) {
+            fin = true;
+            if (v[j] != 0.0) nz = true;
+        }
+    if (__ballot(fin) == 0 || __ballot(nz) == 0) return 0.0;
+    const double med = reg_median<KPL>(v, n);
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) v[j] = (static_cast<int64_t>(j) * 64 + lane < n) ? fabs(v[j] - med) : reg_pad();
+    return reg_median<KPL>(v, n);
+}
+
 struct MedianArgs {
     const double* d1;      // band d_1 of row r at d1 + r*row_stride
     int64_t row_stride;
@@ -448,6 +582,26 @@ __global__ void __launch_bounds__(NT) k_universal_threshold(const MedianArgs a) 
     }
 }
 
+// rows of up to 64 * KPL samples: straight from global memory into registers, one wavefront per row
+template <int KPL>
+__global__ void __launch_bounds__(64) k_universal_threshold_reg(const MedianArgs a) {
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n;
+    const double* __restrict__ d = a.d1 + row * a.row_stride;
+    double v[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int64_t i = static_cast<int64_t>(j) * 64 + lane;
+        v[j] = i < n ? fabs(d[i]) : reg_pad();
+    }
+    const double median = reg_median<KPL>(v, n);
+    if (lane == 0) {
+        const double sigma = median / 0.6745;
+        a.thr_out[row] = sigma * a.sqrt_2_ln_n;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // streaming denoiser: noise window, noise level and multiplier-path threshold, one workgroup per stream
 // ---------------------------------------------------------------------------
@@ -479,6 +633,20 @@ struct StreamNoiseArgs {
     double* thr;            // [nrows]
     int32_t lds_cap;        // a ring or a block up to this length is copied into LDS
 };
+
+// threshold of the multiplier path before the multiplier: UNIVERSAL, SURE (0.8 of it), MINIMAX (piecewise in
+// n), FIXED (sigma itself)
+__device__ __forceinline__ double stream_base_threshold(const StreamNoiseArgs& a, double sigma) {
+#pragma clang fp contract(off)
+    if (a.method == 0) return sigma * a.sqrt_2_ln_n;
+    if (a.method == 1) return sigma * a.sqrt_2_ln_n * 0.8;
+    if (a.method == 2) {
+        if (a.n <= 32) return 0.0;
+        if (a.n <= 64) return sigma * (0.3936 + 0.1829 * a.log_n);
+        return sigma * (0.4745 + 0.1148 * a.log_n);
+    }
+    return sigma;
+}
 
 // MAD of |v_0..n-1| with the reference's guards: 0 when no entry is finite or every finite entry is zero
 template <int NT, typename Src>
@@ -649,24 +817,73 @@ __global__ void __launch_bounds__(NT) k_stream_noise(const StreamNoiseArgs a) {
             sigma = stream_mad<NT>(src, n, sel) / 0.6745;
         }
     }
-    if (tid == 0) {
-        double base;
-        if (a.method == 0) {
-            base = sigma * a.sqrt_2_ln_n;
-        } else if (a.method == 1) {
-            base = sigma * a.sqrt_2_ln_n * 0.8;
-        } else if (a.method == 2) {
-            if (n <= 32)
-                base = 0.0;
-            else if (n <= 64)
-                base = sigma * (0.3936 + 0.1829 * a.log_n);
-            else
-                base = sigma * (0.4745 + 0.1148 * a.log_n);
-        } else {
-            base = sigma;
+    if (tid == 0) a.thr[row] = stream_base_threshold(a, sigma) * a.multiplier;
+}
+
+// The same for rings and blocks of up to 64 * KPL samples, straight from global memory into the registers of
+// one wavefront per stream.  Two kernels (ring + MAD level; threshold of the multiplier path) so that each
+// carries one copy of the selection code.
+template <int KPL>
+__global__ void __launch_bounds__(64) k_stream_ring_mad_reg(const StreamNoiseArgs a) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n, w = a.w;
+    const double* __restrict__ d = a.details + row * a.row_stride;
+    double* win = a.window + row * w;
+    double v[KPL];
+    const unsigned m = static_cast<unsigned>(n <= w ? n : w);
+    const unsigned un = static_cast<unsigned>(n), uw = static_cast<unsigned>(w), i0 = static_cast<unsigned>(a.index0);
+    if (un > uw) {
+        // a block longer than the ring replaces every slot: write the picks, then read the ring back
+        for (unsigned k = lane; k < m; k += 64u) {
+            unsigned slot = i0 + k;
+            if (slot >= uw) slot -= uw;
+            win[slot] = fabs(d[stratified_pick(k, un, uw)]);
         }
-        a.thr[row] = base * a.multiplier;
+        __threadfence_block();
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const unsigned i = static_cast<unsigned>(j) * 64u + lane;
+            v[j] = i < uw ? win[i] : reg_pad();
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const unsigned i = static_cast<unsigned>(j) * 64u + lane;
+            v[j] = reg_pad();
+            if (i < uw) {
+                const unsigned rel = i >= i0 ? i - i0 : i + uw - i0;  // position of slot i in this block's run of picks
+                const double* src = rel < m ? d + rel : win + i;     // a new pick, or the slot's old value (>= 0)
+                v[j] = fabs(*src);
+                if (rel < m) win[i] = v[j];
+            }
+        }
     }
+    const double lvl = reg_mad<KPL>(v, w) / 0.6745;
+    if (lane == 0) a.level[row] = lvl;
+}
+
+template <int KPL>
+__global__ void __launch_bounds__(64) k_stream_threshold_reg(const StreamNoiseArgs a) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n;
+    const double* __restrict__ d = a.details + row * a.row_stride;
+    double sigma = a.level[row];
+    if (sigma <= 0.0 || a.estimation == 2) {
+        // no level to use: the block's own |details| give sigma
+        double v[KPL];
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int64_t i = static_cast<int64_t>(j) * 64 + lane;
+            v[j] = i < n ? fabs(d[i]) : reg_pad();
+        }
+        sigma = reg_mad<KPL>(v, n) / 0.6745;
+    }
+    if (lane == 0) a.thr[row] = stream_base_threshold(a, sigma) * a.multiplier;
 }
 
 // ---------------------------------------------------------------------------

@@ -1027,11 +1027,29 @@ static double host_sqrt_2_ln_n(int64_t n) { return sqrt(2 * log(static_cast<doub
 // rows of up to kWaveSelectMax samples go one wavefront per row, longer rows one 256-lane workgroup per row
 static constexpr int64_t kWaveSelectMax = 2048;
 
+// keys per lane of the register-resident selection kernels for a row of n samples, 0 when it is too long
+static int reg_kpl(int64_t n) {
+    if (getenv("VW_NO_REG_SELECT") != nullptr) return 0;
+    if (n <= 256) return 4;
+    if (n <= 512) return 8;
+    if (n <= 1024) return 16;
+    if (n <= 2048) return 32;
+    return 0;
+}
+
 static void launch_universal_threshold(const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
+    const dim3 grid(static_cast<unsigned>(b));
+    switch (reg_kpl(n)) {
+        case 4: hipLaunchKernelGGL(k_universal_threshold_reg<4>, grid, dim3(64), 0, s, a); return;
+        case 8: hipLaunchKernelGGL(k_universal_threshold_reg<8>, grid, dim3(64), 0, s, a); return;
+        case 16: hipLaunchKernelGGL(k_universal_threshold_reg<16>, grid, dim3(64), 0, s, a); return;
+        case 32: hipLaunchKernelGGL(k_universal_threshold_reg<32>, grid, dim3(64), 0, s, a); return;
+        default: break;
+    }
     if (n <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
-        hipLaunchKernelGGL(k_universal_threshold<64>, dim3(static_cast<unsigned>(b)), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(k_universal_threshold<64>, grid, dim3(64), lds, s, a);
     else
-        hipLaunchKernelGGL(k_universal_threshold<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+        hipLaunchKernelGGL(k_universal_threshold<kThreads>, grid, dim3(kThreads), lds, s, a);
 }
 
 static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels,
@@ -1601,6 +1619,25 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
                 if (n <= a.lds_cap && n > staged) staged = n;
             }
             const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
+            const dim3 grid(static_cast<unsigned>(b));
+            if (do_level == do_update && !(do_level && noise_estimation == VW_NOISE_STD)) {  // MAD, or the threshold alone
+                const int kw = do_update ? reg_kpl(state->window) : 1, kn = want_thr ? reg_kpl(n) : 1;
+                if (kw != 0 && kn != 0) {
+                    if (do_update) switch (kw) {
+                        case 4: hipLaunchKernelGGL(k_stream_ring_mad_reg<4>, grid, dim3(64), 0, s, a); break;
+                        case 8: hipLaunchKernelGGL(k_stream_ring_mad_reg<8>, grid, dim3(64), 0, s, a); break;
+                        case 16: hipLaunchKernelGGL(k_stream_ring_mad_reg<16>, grid, dim3(64), 0, s, a); break;
+                        default: hipLaunchKernelGGL(k_stream_ring_mad_reg<32>, grid, dim3(64), 0, s, a); break;
+                    }
+                    if (want_thr) switch (kn) {
+                        case 4: hipLaunchKernelGGL(k_stream_threshold_reg<4>, grid, dim3(64), 0, s, a); break;
+                        case 8: hipLaunchKernelGGL(k_stream_threshold_reg<8>, grid, dim3(64), 0, s, a); break;
+                        case 16: hipLaunchKernelGGL(k_stream_threshold_reg<16>, grid, dim3(64), 0, s, a); break;
+                        default: hipLaunchKernelGGL(k_stream_threshold_reg<32>, grid, dim3(64), 0, s, a); break;
+                    }
+                    return;
+                }
+            }
             if (longest <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
                 hipLaunchKernelGGL(k_stream_noise<64>, dim3(static_cast<unsigned>(b)), dim3(64), lds, s, a);
             else
