@@ -249,6 +249,51 @@ def streaming_denoise_batch(state, x, wavelet, method=UNIVERSAL, soft=True, mult
     return int(st), out, thr
 
 
+class StreamingTransformState:
+    """One MODWTStreamingTransformImpl (modwt/streaming/MODWTStreamingTransformImpl.java): sliding windows of
+    bufferSize samples that overlap by filter length - 1, each transformed at a single level."""
+
+    def __init__(self, wavelet, buffer_size, boundary=PERIODIC):
+        self.wavelet, self.buffer_size, self.boundary = wavelet, int(buffer_size), boundary
+        self.h, self.g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+        f = lib().vwo_stream_xform_create
+        f.restype = C.c_void_p
+        self.handle = C.c_void_p(f(C.c_int64(self.buffer_size), C.c_int(self.h.size)))
+
+    def process(self, data):
+        """Returns the blocks emitted while `data` was fed sample by sample: [blocks][2][bufferSize] = (detail, approx)."""
+        d = _f64(data)
+        hop = self.buffer_size - (self.h.size - 1)
+        cap = d.size // hop + 2
+        out = np.empty((cap, 2, self.buffer_size))
+        f = lib().vwo_stream_xform_process
+        f.restype = C.c_int64
+        nb = f(self.handle, _p(d), C.c_int64(d.size), _p(self.h), C.c_int(self.h.size), _p(self.g), C.c_int(self.g.size),
+               C.c_int(self.boundary), _p(out), C.c_int64(cap))
+        assert nb <= cap
+        return out[:nb].copy()
+
+    def flush(self):
+        out = np.empty((1, 2, self.buffer_size))
+        nb = lib().vwo_stream_xform_flush(self.handle, _p(self.h), C.c_int(self.h.size), _p(self.g), C.c_int(self.g.size),
+                                          C.c_int(self.boundary), _p(out))
+        return out[:nb].copy()
+
+    def reset(self):
+        lib().vwo_stream_xform_reset(self.handle)
+
+    def level(self):
+        f = lib().vwo_stream_xform_level
+        f.restype = C.c_int64
+        return int(f(self.handle))
+
+    def __del__(self):
+        try:
+            lib().vwo_stream_xform_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def stream_mad(values):
     v = _f64(values)
     f = lib().vwo_stream_mad

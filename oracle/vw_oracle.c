@@ -790,6 +790,88 @@ int vwo_streaming_denoise_batch(const double *x, int64_t b, int64_t n, const dou
 }
 
 /* ------------------------------------------------------------------------ */
+/* modwt/streaming/MODWTStreamingTransformImpl.java: sliding-window block transform */
+/* ------------------------------------------------------------------------ */
+
+/* State of one MODWTStreamingTransformImpl (:54-60): the circular buffer of bufferSize + overlap samples
+ * (overlap = filter length - 1, :93-94), the write position and the count of unconsumed samples. */
+typedef struct {
+    double *ring;
+    int64_t ring_len, buffer_size, overlap, write_pos, in_buffer;
+} vwo_stream_xform;
+
+vwo_stream_xform *vwo_stream_xform_create(int64_t buffer_size, int filter_len) {
+    vwo_stream_xform *s = (vwo_stream_xform *)malloc(sizeof(*s));
+    s->buffer_size = buffer_size;
+    s->overlap = filter_len - 1;
+    s->ring_len = buffer_size + s->overlap;
+    s->ring = (double *)calloc((size_t)s->ring_len, sizeof(double));
+    s->write_pos = 0;
+    s->in_buffer = 0;
+    return s;
+}
+
+void vwo_stream_xform_destroy(vwo_stream_xform *s) {
+    if (s) {
+        free(s->ring);
+        free(s);
+    }
+}
+
+int64_t vwo_stream_xform_level(const vwo_stream_xform *s) { return s->in_buffer; }
+
+/* :188-203 (reset) */
+void vwo_stream_xform_reset(vwo_stream_xform *s) {
+    memset(s->ring, 0, sizeof(double) * (size_t)s->ring_len);
+    s->write_pos = 0;
+    s->in_buffer = 0;
+}
+
+/* :145-188 (process -> processSampleInternal -> processBuffer), sample by sample: every time
+ * bufferSize unconsumed samples are buffered, the last bufferSize samples are transformed (single level)
+ * and bufferSize - overlap of them count as consumed.  Blocks go to out[block][2][bufferSize] = (detail,
+ * approx); returns the number of blocks emitted (at most max_blocks are written). */
+int64_t vwo_stream_xform_process(vwo_stream_xform *s, const double *data, int64_t len, const double *h,
+                                 int lh, const double *g, int lg, int boundary, double *out,
+                                 int64_t max_blocks) {
+    const int64_t bsz = s->buffer_size;
+    int64_t blocks = 0;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)bsz);
+    for (int64_t t = 0; t < len; t++) {
+        s->ring[s->write_pos] = data[t];
+        s->write_pos = (s->write_pos + 1) % s->ring_len;
+        s->in_buffer++;
+        if (s->in_buffer >= bsz) {
+            int64_t read_pos = (s->write_pos - bsz + s->ring_len) % s->ring_len;
+            for (int64_t i = 0; i < bsz; i++) buf[i] = s->ring[(read_pos + i) % s->ring_len];
+            if (blocks < max_blocks)
+                vwo_modwt_forward(buf, bsz, h, lh, g, lg, boundary, out + (blocks * 2 + 1) * bsz,
+                                  out + (blocks * 2) * bsz);
+            blocks++;
+            s->in_buffer -= bsz - s->overlap;
+        }
+    }
+    free(buf);
+    return blocks;
+}
+
+/* :205-231 (flush; close does the same, :255-280): the unconsumed samples, zero-padded to bufferSize,
+ * make one last block; returns 1 if a block was written to out[2][bufferSize], else 0 */
+int vwo_stream_xform_flush(vwo_stream_xform *s, const double *h, int lh, const double *g, int lg,
+                           int boundary, double *out) {
+    if (s->in_buffer <= 0) return 0;
+    const int64_t bsz = s->buffer_size;
+    double *buf = (double *)calloc((size_t)bsz, sizeof(double));
+    int64_t read_pos = (s->write_pos - s->in_buffer + s->ring_len) % s->ring_len;
+    for (int64_t i = 0; i < s->in_buffer; i++) buf[i] = s->ring[(read_pos + i) % s->ring_len];
+    vwo_modwt_forward(buf, bsz, h, lh, g, lg, boundary, out + bsz, out);
+    free(buf);
+    s->in_buffer = 0;
+    s->write_pos = 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------ */
 /* modwt/BatchSIMDMODWT.java (structure-of-arrays batch) and ParallelMultiLevelMODWT.java */
 /* ------------------------------------------------------------------------ */
 

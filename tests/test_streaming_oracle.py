@@ -193,3 +193,46 @@ def test_reference_test_properties():
         y = o.streaming_denoise_batch(st, xs[0], wv, multiplier=mult)[1]
         energies.append(float((y * y).sum()))
     assert energies[0] > energies[1] > energies[2]  # 3.0 removes the whole detail band
+
+
+# ---- modwt/streaming/MODWTStreamingTransformImpl.java ---------------------------------------------------------
+
+def _py_stream_windows(data, buffer_size, overlap):
+    """processSampleInternal / processBuffer (:161-203) statement by statement; returns the windows and the
+    number of unconsumed samples"""
+    ring = [0.0] * (buffer_size + overlap)
+    write, level, windows = 0, 0, []
+    for s in data:
+        ring[write] = s
+        write = (write + 1) % len(ring)
+        level += 1
+        if level >= buffer_size:
+            read = (write - buffer_size + len(ring)) % len(ring)
+            windows.append([ring[(read + i) % len(ring)] for i in range(buffer_size)])
+            level -= buffer_size - overlap
+    return windows, level
+
+
+@pytest.mark.parametrize("wn,bsz", [("haar", 2), ("haar", 16), ("db4", 8), ("db4", 64), ("sym8", 100), ("db4", 256)])
+def test_streaming_transform_windows(wn, bsz):
+    wv = get_wavelet(wn)
+    rng = np.random.default_rng(bsz)
+    data = rng.standard_normal(5 * bsz + 3)
+    st = o.StreamingTransformState(wv, bsz)
+    got = np.concatenate([st.process(data[:7]), st.process(data[7:7 + bsz]), st.process(data[7 + bsz:])])
+    windows, level = _py_stream_windows(data.tolist(), bsz, len(wv.dec_lo) - 1)
+    assert got.shape[0] == len(windows) and st.level() == level
+    want = o.modwt_forward_batch(np.array(windows), wv)
+    assert np.array_equal(got, want)
+    # window k starts at sample k * (bufferSize - overlap): consecutive windows share filter length - 1 samples
+    hop = bsz - (len(wv.dec_lo) - 1)
+    for k, w in enumerate(windows):
+        assert w == data[k * hop:k * hop + bsz].tolist()
+    # flush: the unconsumed samples, zero-padded (:205-231)
+    tail = st.flush()
+    assert tail.shape[0] == (1 if level > 0 else 0)
+    if level > 0:
+        padded = np.zeros(bsz)
+        padded[:level] = data[data.size - level:]
+        assert np.array_equal(tail, o.modwt_forward_batch(padded[None], wv))
+    assert st.level() == 0 and st.flush().shape[0] == 0

@@ -5,7 +5,8 @@ VectorWaveSwtAdapter API over libvwgpu.so (hand-written gfx950 HIP kernels
 behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
 from .api import (BatchSIMDMODWT, BoundaryMode, IllegalStateException, InvalidArgumentException, InvalidSignalException, MODWTResult,
-                  MODWTStreamingDenoiser, MODWTTransform, NoiseEstimation,
+                  InvalidStateException, MODWTStreamingDenoiser, MODWTStreamingTransform, MODWTTransform, NoiseEstimation,
+                  StreamingStatistics,
                   MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult, ParallelMultiLevelMODWT,
                   ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
                   WaveletTransformException)
@@ -16,5 +17,6 @@ __all__ = [
     "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
     "WaveletDenoiser", "ThresholdMethod", "ThresholdType", "BatchSIMDMODWT", "ParallelMultiLevelMODWT",
-    "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException",
+    "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException", "MODWTStreamingTransform",
+    "InvalidStateException", "StreamingStatistics",
 ]
