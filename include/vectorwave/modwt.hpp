@@ -513,4 +513,117 @@ class WaveletDenoiser {
     std::shared_ptr<Context> ctx_;
 };
 
+// modwt/streaming/MODWTStreamingDenoiser.java: block-by-block denoiser whose noise rings live in GPU memory.
+// `streams` > 1 (not in the reference) runs that many denoisers in lock step, one block per stream per call.
+class MODWTStreamingDenoiser {
+  public:
+    enum class NoiseEstimation : int32_t { MAD = VW_NOISE_MAD, STD = VW_NOISE_STD, FIXED = VW_NOISE_FIXED };  // :58-65
+
+    // :367-469, same defaults and argument checks
+    class Builder {
+      public:
+        Builder& wavelet(const Wavelet& w) { wavelet_ = w; return *this; }
+        Builder& boundaryMode(BoundaryMode m) { mode_ = m; return *this; }
+        Builder& bufferSize(int v) { if (v <= 0) throw InvalidArgumentException("Buffer size must be positive", ""); bufferSize_ = v; return *this; }
+        Builder& thresholdType(WaveletDenoiser::ThresholdType t) { type_ = t; return *this; }
+        Builder& thresholdMethod(WaveletDenoiser::ThresholdMethod m) { method_ = m; return *this; }
+        Builder& thresholdMultiplier(double v) { if (!(v > 0)) throw InvalidArgumentException("Threshold multiplier must be positive", ""); multiplier_ = v; return *this; }
+        Builder& noiseEstimation(NoiseEstimation e) { estimation_ = e; return *this; }
+        Builder& noiseWindowSize(int v) { if (v <= 0) throw InvalidArgumentException("Noise window size must be positive", ""); window_ = v; return *this; }
+        Builder& streams(int64_t v) { if (v <= 0) throw InvalidArgumentException("Stream count must be positive", ""); streams_ = v; return *this; }
+        Builder& context(std::shared_ptr<Context> c) { ctx_ = c; return *this; }
+        MODWTStreamingDenoiser build() const { return MODWTStreamingDenoiser(*this); }
+
+      private:
+        friend class MODWTStreamingDenoiser;
+        Wavelet wavelet_ = getWavelet("db4");
+        BoundaryMode mode_ = BoundaryMode::PERIODIC;
+        int bufferSize_ = 256;
+        WaveletDenoiser::ThresholdType type_ = WaveletDenoiser::ThresholdType::SOFT;
+        WaveletDenoiser::ThresholdMethod method_ = WaveletDenoiser::ThresholdMethod::UNIVERSAL;
+        double multiplier_ = 1.0;
+        NoiseEstimation estimation_ = NoiseEstimation::MAD;
+        int window_ = 1024;
+        int64_t streams_ = 1;
+        std::shared_ptr<Context> ctx_ = defaultContext();
+    };
+
+    MODWTStreamingDenoiser(MODWTStreamingDenoiser&& o) noexcept : cfg_(o.cfg_), state_(o.state_), closed_(o.closed_) { o.state_ = nullptr; }
+    MODWTStreamingDenoiser(const MODWTStreamingDenoiser&) = delete;
+    MODWTStreamingDenoiser& operator=(const MODWTStreamingDenoiser&) = delete;
+    ~MODWTStreamingDenoiser() { close(); }
+
+    // :93-127; samples holds one block per stream, [streams][n] row-major
+    std::vector<double> denoise(const std::vector<double>& samples) {
+        if (closed_) throw std::logic_error("Denoiser is closed");  // IllegalStateException
+        if (samples.empty()) throw InvalidArgumentException("Samples cannot be null or empty", "");
+        if (samples.size() % static_cast<size_t>(cfg_.streams_) != 0) throw InvalidArgumentException("expected one block per stream", "");
+        const int64_t n = static_cast<int64_t>(samples.size()) / cfg_.streams_;
+        int64_t bad = -1;
+        cfg_.ctx_->check(vw_first_non_finite(cfg_.ctx_->get(), samples.data(), static_cast<int64_t>(samples.size()), &bad));
+        std::vector<double> y(samples.size());
+        const Wavelet& w = cfg_.wavelet_;
+        const double logN = std::log(static_cast<double>(n));
+        cfg_.ctx_->check(vw_streaming_denoise_batch(cfg_.ctx_->get(), state_, samples.data(), cfg_.streams_, n, w.decLo.data(), static_cast<int32_t>(w.decLo.size()),
+                                                    w.decHi.data(), static_cast<int32_t>(w.decHi.size()), w.recLo.data(), static_cast<int32_t>(w.recLo.size()),
+                                                    w.recHi.data(), static_cast<int32_t>(w.recHi.size()), static_cast<int32_t>(cfg_.mode_), 0u,
+                                                    static_cast<int32_t>(cfg_.method_), cfg_.type_ == WaveletDenoiser::ThresholdType::SOFT ? 1 : 0,
+                                                    cfg_.multiplier_, static_cast<int32_t>(cfg_.estimation_), logN, std::sqrt(2.0 * logN), y.data(), nullptr));
+        return y;
+    }
+    // :332-334, one level per stream
+    std::vector<double> getEstimatedNoiseLevels() const {
+        std::vector<double> lv(static_cast<size_t>(cfg_.streams_), 0.0);
+        if (state_ != nullptr) cfg_.ctx_->check(vw_stream_state_noise_levels(cfg_.ctx_->get(), state_, lv.data()));
+        return lv;
+    }
+    double getEstimatedNoiseLevel() const { return getEstimatedNoiseLevels()[0]; }
+    int64_t getSamplesProcessed() const { return state_ != nullptr ? vw_stream_state_samples_processed(state_) : finalSamples_; }  // :341-343
+    bool isClosed() const { return closed_; }
+    void close() {  // :351-355
+        if (state_ != nullptr) {
+            finalSamples_ = vw_stream_state_samples_processed(state_);
+            vw_stream_state_destroy(cfg_.ctx_->get(), state_);
+            state_ = nullptr;
+        }
+        closed_ = true;
+    }
+
+  private:
+    explicit MODWTStreamingDenoiser(const Builder& b) : cfg_(b) {
+        cfg_.ctx_->check(vw_stream_state_create(cfg_.ctx_->get(), cfg_.streams_, cfg_.window_, &state_));
+    }
+    Builder cfg_;
+    vw_stream_state* state_ = nullptr;
+    bool closed_ = false;
+    int64_t finalSamples_ = 0;
+};
+
+// modwt/BatchSIMDMODWT.java: single-level PERIODIC MODWT over a sample-major batch, soa[t * batch + b]
+struct BatchSIMDMODWT {
+    // :64-81
+    static void batchMODWTSoA(const std::vector<double>& soaSignals, std::vector<double>& soaApprox, std::vector<double>& soaDetail, const Wavelet& wavelet,
+                              int64_t batchSize, int64_t signalLength, std::shared_ptr<Context> ctx = defaultContext()) {
+        const size_t count = static_cast<size_t>(batchSize) * static_cast<size_t>(signalLength);
+        if (soaSignals.size() < count) throw std::out_of_range("soaSignals shorter than batchSize * signalLength");
+        soaApprox.resize(count);
+        soaDetail.resize(count);
+        ctx->check(vw_batch_modwt_soa(ctx->get(), soaSignals.data(), batchSize, signalLength, wavelet.decLo.data(), static_cast<int32_t>(wavelet.decLo.size()),
+                                      wavelet.decHi.data(), static_cast<int32_t>(wavelet.decHi.size()), wavelet.name == "haar" ? 1 : 0, soaApprox.data(),
+                                      soaDetail.data()));
+    }
+    // :282-291: soa[t * batch + b] = signals[b][t]
+    static void convertToSoA(const std::vector<double>& signals, int64_t batchSize, int64_t signalLength, std::vector<double>& soaOutput,
+                             std::shared_ptr<Context> ctx = defaultContext()) {
+        soaOutput.resize(signals.size());
+        ctx->check(vw_transpose(ctx->get(), signals.data(), batchSize, signalLength, soaOutput.data()));
+    }
+    // :299-308
+    static void convertFromSoA(const std::vector<double>& soaData, int64_t batchSize, int64_t signalLength, std::vector<double>& output,
+                               std::shared_ptr<Context> ctx = defaultContext()) {
+        output.resize(soaData.size());
+        ctx->check(vw_transpose(ctx->get(), soaData.data(), signalLength, batchSize, output.data()));
+    }
+};
+
 }  // namespace vectorwave

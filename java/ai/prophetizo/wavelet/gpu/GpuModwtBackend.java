@@ -9,6 +9,7 @@ import ai.prophetizo.wavelet.exception.InvalidSignalException;
 import java.lang.foreign.Arena;
 import java.lang.foreign.MemorySegment;
 
+import static java.lang.foreign.ValueLayout.ADDRESS;
 import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
 import static java.lang.foreign.ValueLayout.JAVA_LONG;
 
@@ -159,6 +160,107 @@ public final class GpuModwtBackend implements AutoCloseable {
                 MemorySegment.copy(y, JAVA_DOUBLE, (long) i * n * Double.BYTES, out[i], 0, n);
             }
             return out;
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /**
+     * State of {@code streams} lock-step MODWTStreamingDenoiser instances (noise rings and levels in GPU memory).
+     * One per MODWTStreamingDenoiser object (streams == 1) or per channel group; release with
+     * {@link #destroyStreamState}.
+     */
+    public MemorySegment createStreamState(long streams, int noiseWindowSize) {
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment out = a.allocate(ADDRESS);
+            int st = (int) VwGpuNative.VW_STREAM_STATE_CREATE.invokeExact(ctx, streams, (long) noiseWindowSize, out);
+            check(st, -1);
+            return out.get(ADDRESS, 0);
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    public void destroyStreamState(MemorySegment state) {
+        try {
+            int st = (int) VwGpuNative.VW_STREAM_STATE_DESTROY.invokeExact(ctx, state);
+            check(st, -1);
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /** MODWTStreamingDenoiser.getEstimatedNoiseLevel() of every stream of the state. */
+    public double[] estimatedNoiseLevels(MemorySegment state, int streams) {
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment lv = a.allocate(JAVA_DOUBLE, streams);
+            int st = (int) VwGpuNative.VW_STREAM_STATE_NOISE_LEVELS.invokeExact(ctx, state, lv);
+            check(st, -1);
+            return lv.toArray(JAVA_DOUBLE);
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /**
+     * MODWTStreamingDenoiser.denoise(samples) for one block per stream of the state: blocks[streams][n].
+     * method: ThresholdMethod.ordinal(); noiseEstimation: NoiseEstimation.ordinal() (MAD, STD, FIXED).
+     */
+    public double[][] streamingDenoise(MemorySegment state, double[][] blocks, Wavelet w, BoundaryMode mode, int method,
+                                       boolean soft, double thresholdMultiplier, int noiseEstimation) {
+        int b = blocks.length;
+        int n = b == 0 ? 0 : blocks[0].length;
+        double[][] out = new double[b][n];
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment x = pack(a, blocks, n);
+            MemorySegment y = a.allocate(JAVA_DOUBLE, (long) b * n);
+            double[] h = w.lowPassDecomposition();
+            double[] g = w.highPassDecomposition();
+            double[] hr = w.lowPassReconstruction();
+            double[] gr = w.highPassReconstruction();
+            // Math.log / Math.sqrt stay on the JVM so that the thresholds match the CPU path bit for bit
+            double logN = Math.log(n);
+            int st = (int) VwGpuNative.VW_STREAMING_DENOISE.invokeExact(ctx, state, x, (long) b, (long) n, taps(a, h), h.length,
+                taps(a, g), g.length, taps(a, hr), hr.length, taps(a, gr), gr.length, boundary(mode), 0, method, soft ? 1 : 0,
+                thresholdMultiplier, noiseEstimation, logN, Math.sqrt(2.0 * logN), y, MemorySegment.NULL);
+            check(st, -1);
+            for (int i = 0; i < b; i++) {
+                MemorySegment.copy(y, JAVA_DOUBLE, (long) i * n * Double.BYTES, out[i], 0, n);
+            }
+            return out;
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /**
+     * BatchSIMDMODWT.batchMODWTSoA: single-level PERIODIC MODWT of a sample-major batch, soa[t * batchSize + b].
+     */
+    public void batchMODWTSoA(double[] soaSignals, double[] soaApprox, double[] soaDetail, Wavelet w, int batchSize,
+                              int signalLength) {
+        long count = (long) batchSize * signalLength;
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment in = a.allocate(JAVA_DOUBLE, count);
+            MemorySegment.copy(soaSignals, 0, in, JAVA_DOUBLE, 0, (int) count);
+            MemorySegment ap = a.allocate(JAVA_DOUBLE, count);
+            MemorySegment de = a.allocate(JAVA_DOUBLE, count);
+            double[] h = w.lowPassDecomposition();
+            double[] g = w.highPassDecomposition();
+            int st = (int) VwGpuNative.VW_BATCH_MODWT_SOA.invokeExact(ctx, in, (long) batchSize, (long) signalLength, taps(a, h),
+                h.length, taps(a, g), g.length, w instanceof ai.prophetizo.wavelet.api.Haar ? 1 : 0, ap, de);
+            check(st, -1);
+            MemorySegment.copy(ap, JAVA_DOUBLE, 0, soaApprox, 0, (int) count);
+            MemorySegment.copy(de, JAVA_DOUBLE, 0, soaDetail, 0, (int) count);
         } catch (RuntimeException e) {
             throw e;
         } catch (Throwable t) {

@@ -70,6 +70,29 @@ public final class VwGpuNative {
     static final MethodHandle VW_DENOISER_THRESHOLDS = h("vw_denoiser_thresholds_batch",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_INT, JAVA_INT,
             JAVA_DOUBLE, ADDRESS));
+    // noise estimation of the streaming denoiser (vw_noise_estimation)
+    public static final int NOISE_MAD = 0, NOISE_STD = 1, NOISE_FIXED = 2;
+    // int32 vw_stream_state_create(ctx, streams, window_size, out_state)
+    static final MethodHandle VW_STREAM_STATE_CREATE = h("vw_stream_state_create",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+    static final MethodHandle VW_STREAM_STATE_DESTROY = h("vw_stream_state_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+    // int32 vw_stream_state_noise_levels(ctx, state, levels)
+    static final MethodHandle VW_STREAM_STATE_NOISE_LEVELS = h("vw_stream_state_noise_levels",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+    static final MethodHandle VW_STREAM_STATE_SAMPLES = h("vw_stream_state_samples_processed", FunctionDescriptor.of(JAVA_LONG, ADDRESS));
+    // int32 vw_streaming_denoise_batch(ctx, state, x, b, n, h, lh, g, lg, hr, lhr, gr, lgr, boundary, flags, method, soft,
+    //                                  threshold_multiplier, noise_estimation, log_n, sqrt_2_ln_n, y, thresholds_out)
+    static final MethodHandle VW_STREAMING_DENOISE = h("vw_streaming_denoise_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS,
+            JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_DOUBLE, JAVA_INT, JAVA_DOUBLE, JAVA_DOUBLE,
+            ADDRESS, ADDRESS));
+    // int32 vw_batch_modwt_soa(ctx, soa_signals, batch, n, h, lh, g, lg, is_haar, soa_approx, soa_detail)
+    static final MethodHandle VW_BATCH_MODWT_SOA = h("vw_batch_modwt_soa",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS,
+            ADDRESS));
+    // int32 vw_transpose(ctx, in, rows, cols, out)
+    static final MethodHandle VW_TRANSPOSE = h("vw_transpose",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
     // int32 vw_swt_universal_threshold_batch(ctx, coeffs, b, n, levels, sqrt_2_ln_n, thresholds)
     static final MethodHandle VW_UNIVERSAL_THRESHOLD = h("vw_swt_universal_threshold_batch",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_DOUBLE, ADDRESS));

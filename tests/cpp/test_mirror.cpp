@@ -17,6 +17,9 @@ int vwo_swt_denoise_batch(const double*, int64_t, int64_t, int, const double*, i
 void vwo_modwt_forward_batch(const double*, int64_t, int64_t, const double*, int, const double*, int, int, double*);
 int vwo_wavelet_denoise_batch(const double*, int64_t, int64_t, int, const double*, int, const double*, int, const double*, int, const double*, int,
                               int, int, double, int, double*, double*);
+int vwo_streaming_denoise_batch(const double*, int64_t, int64_t, const double*, int, const double*, int, const double*, int, const double*, int, int, int,
+                                int, double, int, double*, int64_t, int64_t*, double*, double*, double*);
+void vwo_batch_modwt_soa(const double*, double*, double*, const double*, const double*, int, int, int64_t, int64_t);
 }
 
 using namespace vectorwave;
@@ -163,6 +166,52 @@ int main() {
         threw = false;
         try { d.denoiseMultiLevel(x, 3, M::FIXED, T::SOFT); } catch (const InvalidArgumentException&) { threw = true; }
         CHECK(threw);
+    }
+    {
+        // MODWTStreamingDenoiser: three lock-step streams over four blocks, MAD and STD, with and without a multiplier
+        const Wavelet& w = getWavelet("db4");
+        using E = MODWTStreamingDenoiser::NoiseEstimation;
+        const int64_t streams = 3, n = 200, window = 128;
+        for (int est = 0; est < 2; ++est)
+            for (double mult : {1.0, 1.5}) {
+                MODWTStreamingDenoiser den = MODWTStreamingDenoiser::Builder().noiseWindowSize(window).streams(streams).thresholdMultiplier(mult)
+                                                 .noiseEstimation(static_cast<E>(est)).build();
+                std::vector<double> ring(streams * window, 0.0), level(streams, 0.0);
+                int64_t index = 0;
+                for (int blk = 0; blk < 4; ++blk) {
+                    auto x = make_signal(streams * n, 100 + blk);
+                    std::vector<double> want(x.size()), thr(streams);
+                    CHECK(vwo_streaming_denoise_batch(x.data(), streams, n, w.decLo.data(), 8, w.decHi.data(), 8, w.recLo.data(), 8, w.recHi.data(), 8, 0, 0,
+                                                      1, mult, est, ring.data(), window, &index, level.data(), want.data(), thr.data()) == 0);
+                    CHECK(bits_equal(den.denoise(x), want));
+                    CHECK(bits_equal(den.getEstimatedNoiseLevels(), level));
+                }
+                CHECK(den.getSamplesProcessed() == 4 * n);
+                den.close();
+                bool threw = false;
+                try { den.denoise(std::vector<double>(streams * n, 0.0)); } catch (const std::logic_error&) { threw = true; }
+                CHECK(threw);
+            }
+    }
+    {
+        // BatchSIMDMODWT: the three arithmetic flavours against the oracle, and the layout round trip
+        const int64_t batch = 37, n = 64;
+        auto aos = make_signal(batch * n, 9);
+        std::vector<double> soa, back;
+        BatchSIMDMODWT::convertToSoA(aos, batch, n, soa);
+        for (int64_t b = 0; b < batch; ++b)
+            for (int64_t t = 0; t < n; t += 13) CHECK(soa[t * batch + b] == aos[b * n + t]);
+        BatchSIMDMODWT::convertFromSoA(soa, batch, n, back);
+        CHECK(bits_equal(back, aos));
+        for (const char* name : {"haar", "db2", "db4"}) {
+            const Wavelet& w = getWavelet(name);
+            std::vector<double> a, d, wa(batch * n), wd(batch * n);
+            BatchSIMDMODWT::batchMODWTSoA(soa, a, d, w, batch, n);
+            vwo_batch_modwt_soa(soa.data(), wa.data(), wd.data(), w.decLo.data(), w.decHi.data(), (int)w.decLo.size(), std::string(name) == "haar" ? 1 : 0,
+                                batch, n);
+            CHECK(bits_equal(a, wa));
+            CHECK(bits_equal(d, wd));
+        }
     }
     std::printf(failures == 0 ? "cpp mirror: all checks passed\n" : "cpp mirror: %d checks FAILED\n", failures);
     return failures == 0 ? 0 : 1;
