@@ -1,0 +1,78 @@
+"""Seeded random sweep over wavelet x length x depth x boundary x batch for the three C-ABI families
+(forward/inverse, SWT denoise, WaveletDenoiser): the HIP path against the oracle, bit for bit.  The fixed
+parity cases pin the shapes that matter; this sweep looks for the shapes nobody thought of (ragged lengths
+around tile and chunk edges, single rows, depth limits, filters longer than the signal)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from vectorwave_amd import _native as N
+from vectorwave_amd.wavelets import get_wavelet
+
+from util import assert_bits_equal, gpu_denoise, gpu_forward, gpu_inverse
+
+pytestmark = pytest.mark.gpu
+
+WAVELETS = ["haar", "db2", "sym3", "db4", "db6", "db10", "sym4", "sym8", "sym11", "coif1", "coif3", "bior2.2", "bior4.4", "bior3.5", "rbio1.3", "db20"]
+EDGES = [1, 2, 3, 7, 8, 9, 31, 63, 64, 65, 255, 256, 257, 479, 480, 481, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049,
+         4095, 4096, 4097, 6143, 6145, 8191, 8193]
+
+
+def _cases(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        wn = WAVELETS[rng.integers(len(WAVELETS))]
+        n = int(EDGES[rng.integers(len(EDGES))] if rng.random() < 0.6 else rng.integers(1, 9000))
+        mode = int(rng.integers(3))
+        b = int(rng.integers(1, 5))
+        jmax = o.max_levels(n, len(get_wavelet(wn).dec_lo))
+        j = int(rng.integers(1, max(jmax, 1) + 1))
+        out.append((wn, n, j, b, mode, int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250101, 120))
+def test_random_forward_inverse(ctx, wn, n, j, b, mode, seed):
+    w = get_wavelet(wn)
+    x = np.ascontiguousarray(np.random.default_rng(seed).standard_normal((b, n)))
+    st, want = o.decompose_batch(x, w, j, mode)
+    gst, got, _ = gpu_forward(ctx, x, wn, j, mode)
+    if st != 0:
+        assert gst == N.VW_E_LEVEL  # beyond the reference's level limit
+        return
+    assert gst == 0, ctx.last_error()
+    assert_bits_equal(got, want, "forward %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    gst, gotx, _ = gpu_inverse(ctx, want, wn, mode)
+    if len(w.rec_hi) < len(w.rec_lo) and mode != 2:
+        assert gst == N.VW_E_LENGTH_MISMATCH  # the reference indexes out of bounds here
+        return
+    assert gst == 0, ctx.last_error()
+    assert_bits_equal(gotx, o.reconstruct_batch(want, w, mode), "inverse %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+
+
+@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250202, 60))
+def test_random_denoise(ctx, wn, n, j, b, mode, seed):
+    w = get_wavelet(wn)
+    if len(w.rec_hi) < len(w.rec_lo) and mode != 2:
+        pytest.skip("the reference cannot invert this wavelet")
+    rng = np.random.default_rng(seed)
+    x = np.ascontiguousarray(np.sin(np.arange(n) / 5.0)[None] + 0.3 * rng.standard_normal((b, n)))
+    soft = bool(seed & 1)
+    thr = -1.0 if seed & 2 else 0.2
+    st, want = o.swt_denoise_batch(x, w, j, thr, soft, mode)
+    gst, got, _ = gpu_denoise(ctx, x, wn, j, mode, thr, soft)
+    if st != 0:
+        assert gst == N.VW_E_LEVEL
+        return
+    assert gst == 0, ctx.last_error()
+    assert_bits_equal(got, want, "swt denoise %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    method = [o.UNIVERSAL, o.MINIMAX, o.BAYES][seed % 3]
+    if n > 2000:
+        return
+    st, wantd, wthr = o.wavelet_denoise_batch(x, w, j, method, soft, mode)
+    from vectorwave_amd import BoundaryMode, ThresholdType, WaveletDenoiser
+    gotd, gthr = WaveletDenoiser(w, BoundaryMode(mode), ctx).denoise_block(x, j, method, ThresholdType.SOFT if soft else ThresholdType.HARD,
+                                                                         return_thresholds=True)
+    assert_bits_equal(gthr, wthr, "WaveletDenoiser thresholds %s N=%d J=%d method=%d" % (wn, n, j, method))
+    assert_bits_equal(gotd, wantd, "WaveletDenoiser %s N=%d J=%d method=%d" % (wn, n, j, method))

@@ -211,6 +211,38 @@ def test_median_with_duplicates_and_zeros(ctx):
         assert_bits_equal(thr, want, "median n=%d" % n)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 127, 128, 256, 257, 480, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095,
+                               4097, 5000])
+def test_median_selection_edge_cases(ctx, n):
+    # every row-length class of the selection kernels (registers up to 2048 samples, LDS up to 4096, global
+    # beyond), with the value patterns that stress an order-statistic search: few distinct values, one
+    # outlier, denormals next to huge values, powers of two (keys that differ in one bit), signed zeros,
+    # values that differ only in the last mantissa bit
+    rng = np.random.default_rng(n)
+    rows = [
+        rng.standard_normal(n),
+        np.round(rng.standard_normal(n), 0),
+        np.full(n, -3.5),
+        np.concatenate([np.zeros(n - 1), [7.0]]),
+        rng.choice([5e-324, 1e-310, 1e-300, 1.0, 1e300, 1.7e308], n),
+        2.0 ** rng.integers(-40, 40, n),
+        rng.choice([0.0, -0.0, 1.0, -1.0], n),
+        1.0 + rng.integers(0, 3, n) * 2.0 ** -52,
+        np.arange(n, dtype=np.float64) - n // 2,
+        np.where(np.arange(n) % 2 == 0, 1.0, 2.0),
+    ]
+    d1 = np.ascontiguousarray(np.array(rows))
+    b = d1.shape[0]
+    coeffs = np.zeros((b, 2, n))
+    coeffs[:, 0] = d1
+    thr = np.empty(b)
+    s2 = math.sqrt(2 * math.log(n)) if n > 1 else 0.0
+    st = ctx.lib.vw_swt_universal_threshold_batch(ctx.handle, C.c_void_p(coeffs.ctypes.data), b, n, 1, s2, C.c_void_p(thr.ctypes.data))
+    assert st == 0, ctx.last_error()
+    want = np.array([o.estimate_noise_sigma(d1[i]) * s2 for i in range(b)])
+    assert_bits_equal(thr, want, "median n=%d" % n)
+
+
 def test_thresholds_and_raw_convolutions(ctx):
     from vectorwave_amd import WaveletOperations as W
     c = signals(1, 1001, seed=1)[0]

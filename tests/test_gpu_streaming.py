@@ -77,6 +77,26 @@ def test_rings_and_blocks_longer_than_the_lds_stage(ctx):
     _run_and_compare(ctx, "db4", 2, 7001, 6144, 2, P, o.SURE, False, 0.9, o.NOISE_FIXED, seed=3)
 
 
+@pytest.mark.parametrize("window", [1, 2, 3, 64, 65, 255, 256, 257, 1024, 1025, 2048, 2049, 5000])
+def test_mad_over_awkward_rings(ctx, window):
+    # rings of every length class (registers up to 2048 entries, LDS, global) fed blocks whose details repeat,
+    # vanish or span the whole exponent range: both medians of the MAD must still be the exact order statistics
+    w = get_wavelet("haar")
+    rng = np.random.default_rng(window)
+    n = 96
+    blocks = [np.round(rng.standard_normal((4, n)), 0), np.zeros((4, n)), rng.choice([1e-300, 1.0, 1e300], (4, n)),
+              rng.standard_normal((4, n)), np.tile(rng.standard_normal((4, 2)), (1, n // 2)), rng.standard_normal((4, n)) * 1e-160]
+    for mult in (1.0, 0.5):
+        state = o.StreamingDenoiserState(4, window)
+        with _build(ctx, "haar", 4, window, mult=mult) as den:
+            for k, blk in enumerate(blocks):
+                blk = np.ascontiguousarray(blk)
+                st, want, _ = o.streaming_denoise_batch(state, blk, w, o.UNIVERSAL, True, mult, o.NOISE_MAD, P)
+                assert st == 0
+                assert_bits_equal(den.denoise(blk), want, "block %d ring %d" % (k, window))
+                assert_bits_equal(den.getEstimatedNoiseLevel(), state.level, "level after block %d ring %d" % (k, window))
+
+
 def test_constant_and_zero_blocks(ctx):
     # all-zero details leave MAD and STD at 0 and the multiplier path at threshold 0
     w = get_wavelet("haar")
