@@ -436,12 +436,18 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
     return v;
 }
 
-template <int KPL>
+// keys below threshold t; HI32: the low word of t is zero, so the high words decide (a 32-bit compare per key
+// instead of a 64-bit one)
+template <int KPL, bool HI32>
 __device__ __forceinline__ unsigned count_below(const double (&v)[KPL], unsigned long long t) {
     unsigned c = 0;
+    const unsigned th = static_cast<unsigned>(t >> 32);
 #pragma unroll
-    for (int j = 0; j < KPL; ++j)
-        c += static_cast<unsigned>(__popcll(__ballot(static_cast<unsigned long long>(__double_as_longlong(v[j])) < t)));
+    for (int j = 0; j < KPL; ++j) {
+        const bool lt = HI32 ? static_cast<unsigned>(__double2hiint(v[j])) < th
+                             : static_cast<unsigned long long>(__double_as_longlong(v[j])) < t;
+        c += static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(lt)));
+    }
     return c;
 }
 
@@ -470,11 +476,19 @@ __device__ __forceinline__ unsigned long long reg_select(const double (&v)[KPL],
     while (pos > 0 && in_range > 1) {
         const int step = pos >= 2 ? 2 : 1;
         pos -= step;
-        const unsigned c1 = count_below<KPL>(v, prefix | (1ull << pos));
-        unsigned c2 = below + in_range, c3 = below + in_range;
-        if (step == 2) {
-            c2 = count_below<KPL>(v, prefix | (2ull << pos));
-            c3 = count_below<KPL>(v, prefix | (3ull << pos));
+        unsigned c1, c2 = below + in_range, c3 = below + in_range;
+        if (pos >= 32) {
+            c1 = count_below<KPL, true>(v, prefix | (1ull << pos));
+            if (step == 2) {
+                c2 = count_below<KPL, true>(v, prefix | (2ull << pos));
+                c3 = count_below<KPL, true>(v, prefix | (3ull << pos));
+            }
+        } else {
+            c1 = count_below<KPL, false>(v, prefix | (1ull << pos));
+            if (step == 2) {
+                c2 = count_below<KPL, false>(v, prefix | (2ull << pos));
+                c3 = count_below<KPL, false>(v, prefix | (3ull << pos));
+            }
         }
         const unsigned end = below + in_range;
         unsigned q, lo_c, hi_c;
@@ -537,7 +551,7 @@ __device__ __forceinline__ double reg_mad(double (&v)[KPL], int64_t n) {
             fin = true;
             if (v[j] != 0.0) nz = true;
         }
-    if (__ballot(fin) == 0 || __ballot(nz) == 0) return 0.0;
+    if (__builtin_amdgcn_ballot_w64(fin) == 0 || __builtin_amdgcn_ballot_w64(nz) == 0) return 0.0;
     const double med = reg_median<KPL>(v, n);
 #pragma unroll
     for (int j = 0; j < KPL; ++j) v[j] = (static_cast<int64_t>(j) * 64 + lane < n) ? fabs(v[j] - med) : reg_pad();
