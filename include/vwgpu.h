@@ -352,6 +352,31 @@ int32_t vw_swt_universal_threshold_batch_dev(vw_ctx *ctx, const double *coeffs_d
                                              int64_t n, int32_t levels, double sqrt_2_ln_n,
                                              double *thresholds_dev, void *stream);
 
+/* ---- sparse detail bands ------------------------------------------------------ */
+
+/* SWTResult.toSparse(threshold) (swt/SWTResult.java:190-222, SparseVector :262-290) for a batch of
+ * decompositions coeffs [B][levels+1][N]: per detail band (row r, level j) the entries with
+ * |v| > threshold, in index order.  Two calls: with indices == NULL, counts[r*levels + j] receives the
+ * number of entries of each band; with indices/values given, the entries of band (r, j) are written at
+ * offsets[r*levels + j] (the caller's exclusive prefix sum of the counts, B*levels + 1 entries, the last
+ * one the total).  The approximation band stays
+ * dense, as in the reference.  The _dev variant takes device pointers for everything. */
+int32_t vw_swt_sparsify_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n, int32_t levels,
+                              double threshold, int64_t *counts, const int64_t *offsets, int32_t *indices,
+                              double *values);
+int32_t vw_swt_sparsify_batch_dev(vw_ctx *ctx, const double *coeffs_dev, int64_t b, int64_t n,
+                                  int32_t levels, double threshold, int64_t *counts_dev,
+                                  const int64_t *offsets_dev, int32_t *indices_dev, double *values_dev,
+                                  void *stream);
+/* SparseSWTResult.toFull() (:225-231, SparseVector.toDense :292-298): detail bands of coeffs_out
+ * [B][levels+1][N] are zeroed and the entries scattered back; offsets has B*levels + 1 entries; the
+ * approximation band of coeffs_out is left untouched. */
+int32_t vw_swt_densify_batch(vw_ctx *ctx, const int64_t *offsets, const int32_t *indices, const double *values,
+                             int64_t b, int64_t n, int32_t levels, double *coeffs_out);
+int32_t vw_swt_densify_batch_dev(vw_ctx *ctx, const int64_t *offsets_dev, const int32_t *indices_dev,
+                                 const double *values_dev, int64_t b, int64_t n, int32_t levels,
+                                 double *coeffs_out_dev, void *stream);
+
 /* ---- thresholding ------------------------------------------------------- */
 
 /* Element-wise thresholding, out of place (out may alias in).  Replaces

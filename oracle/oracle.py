@@ -294,6 +294,25 @@ class StreamingTransformState:
             pass
 
 
+def sparse_vector(dense, threshold):
+    """SWTResult.SparseVector (swt/SWTResult.java:267-290): (indices int32, values) of |v| > threshold."""
+    d = _f64(dense)
+    f = lib().vwo_sparse_vector
+    f.restype = C.c_int64
+    idx = np.empty(d.size, dtype=np.int32)
+    val = np.empty(d.size)
+    cnt = f(_p(d), C.c_int64(d.size), C.c_double(threshold), idx.ctypes.data_as(C.POINTER(C.c_int32)), _p(val))
+    return idx[:cnt].copy(), val[:cnt].copy()
+
+
+def sparse_to_dense(indices, values, n):
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    val = _f64(values)
+    out = np.empty(n)
+    lib().vwo_sparse_to_dense(idx.ctypes.data_as(C.POINTER(C.c_int32)), _p(val), C.c_int64(idx.size), C.c_int64(n), _p(out))
+    return out
+
+
 def stream_mad(values):
     v = _f64(values)
     f = lib().vwo_stream_mad

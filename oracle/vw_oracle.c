@@ -872,6 +872,30 @@ int vwo_stream_xform_flush(vwo_stream_xform *s, const double *h, int lh, const d
 }
 
 /* ------------------------------------------------------------------------ */
+/* swt/SWTResult.java: sparse detail bands */
+/* ------------------------------------------------------------------------ */
+
+/* SWTResult.SparseVector(dense, threshold) (swt/SWTResult.java:267-290): the entries with
+ * Math.abs(v) > threshold in index order; returns their number (indices/values may be NULL to count). */
+int64_t vwo_sparse_vector(const double *dense, int64_t n, double threshold, int32_t *indices, double *values) {
+    int64_t count = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (fabs(dense[i]) > threshold) {
+            if (indices) indices[count] = (int32_t)i;
+            if (values) values[count] = dense[i];
+            count++;
+        }
+    }
+    return count;
+}
+
+/* SparseVector.toDense (:292-298) */
+void vwo_sparse_to_dense(const int32_t *indices, const double *values, int64_t count, int64_t n, double *dense) {
+    for (int64_t i = 0; i < n; i++) dense[i] = 0.0;
+    for (int64_t i = 0; i < count; i++) dense[indices[i]] = values[i];
+}
+
+/* ------------------------------------------------------------------------ */
 /* modwt/BatchSIMDMODWT.java (structure-of-arrays batch) and ParallelMultiLevelMODWT.java */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,100 @@
+"""swt/SWTResult.java sparse form: the oracle against a direct reading of SparseVector (CPU), and the GPU
+compaction / expansion against the oracle, bit for bit and in index order (GPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+
+def _band(n, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(n)
+    v[rng.random(n) < 0.3] = 0.0
+    return v
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 256, 1000])
+@pytest.mark.parametrize("thr", [0.0, 0.5, 10.0])
+def test_oracle_sparse_vector(n, thr):
+    d = _band(n, n)
+    idx, val = o.sparse_vector(d, thr)
+    keep = [i for i in range(n) if abs(d[i]) > thr]  # SWTResult.java:270-288
+    assert idx.tolist() == keep and np.array_equal(val, d[keep])
+    back = o.sparse_to_dense(idx, val, n)
+    want = np.where(np.abs(d) > thr, d, 0.0)
+    assert np.array_equal(back, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,levels", [(1, 1, 1), (3, 17, 2), (2, 1023, 3), (2, 1024, 4), (3, 1025, 2), (2, 5000, 5), (1, 70001, 2)])
+@pytest.mark.parametrize("thr", [0.0, 0.7, 100.0])
+def test_gpu_sparsify_densify(ctx, b, n, levels, thr):
+    from vectorwave_amd import _native as N
+    rng = np.random.default_rng(n + levels)
+    coeffs = rng.standard_normal((b, levels + 1, n))
+    coeffs[rng.random(coeffs.shape) < 0.25] = 0.0
+    coeffs[0, 0, 0] = -0.0
+    counts = np.full(b * levels, -1, dtype=np.int64)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), b, n, levels, thr, vp(counts), None, None, None) == N.VW_OK
+    want = [o.sparse_vector(coeffs[r, j], thr) for r in range(b) for j in range(levels)]
+    assert counts.tolist() == [w[0].size for w in want]
+    offsets = np.zeros(b * levels + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    idx = np.full(max(total, 1), -1, dtype=np.int32)
+    val = np.full(max(total, 1), np.nan)
+    assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), b, n, levels, thr, None, vp(offsets), vp(idx), vp(val)) == N.VW_OK
+    for k, (wi, wv) in enumerate(want):
+        lo, hi = offsets[k], offsets[k + 1]
+        assert np.array_equal(idx[lo:hi], wi), "indices of band %d" % k
+        assert np.array_equal(val[lo:hi].view(np.uint64), wv.view(np.uint64)), "values of band %d" % k
+    out = np.full_like(coeffs, 7.0)
+    assert ctx.lib.vw_swt_densify_batch(ctx.handle, vp(offsets), vp(idx), vp(val), b, n, levels, vp(out)) == N.VW_OK
+    assert np.all(out[:, levels] == 7.0)  # the approximation band is the caller's
+    for r in range(b):
+        for j in range(levels):
+            wi, wv = want[r * levels + j]
+            assert np.array_equal(out[r, j].view(np.uint64), o.sparse_to_dense(wi, wv, n).view(np.uint64))
+
+
+@pytest.mark.gpu
+def test_swt_result_mirror(ctx):
+    from vectorwave_amd import SWTResult
+    rng = np.random.default_rng(5)
+    n, levels = 300, 3
+    a = rng.standard_normal(n)
+    d = rng.standard_normal((levels, n)) * np.array([1.0, 0.1, 0.01])[:, None]
+    res = SWTResult(a, d, levels, ctx)
+    assert res.getLevels() == levels and res.getSignalLength() == n
+    assert np.array_equal(res.getDetail(1), d[1]) and np.array_equal(res.getApproximation(), a)
+    e = sum(float(v) * float(v) for v in a)
+    assert res.getApproximationEnergy() == e
+    total = e
+    for k in range(levels):
+        total += res.getDetailEnergy(k)  # SWTResult.java:168-181: approximation first, then level by level
+    assert res.getTotalEnergy() == total
+    sp = res.toSparse(0.05)
+    assert sp.getThreshold() == 0.05
+    kept = 0
+    for k in range(levels):
+        wi, wv = o.sparse_vector(d[k], 0.05)
+        gi, gv = sp.getSparseDetail(k)
+        assert np.array_equal(gi, wi) and np.array_equal(gv, wv)
+        kept += wi.size
+    assert sp.getCompressionRatio() == (n * (levels + 1)) / (n + 2 * kept)  # SWTResult.java:238-247
+    full = sp.toFull()
+    assert np.array_equal(full.getApproximation(), a)
+    assert np.array_equal(full.getAllDetails(), np.where(np.abs(d) > 0.05, d, 0.0))
+    assert full == SWTResult(a, np.where(np.abs(d) > 0.05, d, 0.0), levels, ctx) and full != res
+    assert hash(full) == hash(SWTResult(a, np.where(np.abs(d) > 0.05, d, 0.0), levels, ctx))
+    with pytest.raises(ValueError):
+        SWTResult(a, d, levels + 1)
+    with pytest.raises(ValueError):
+        SWTResult(a, [d[0], d[1][:-1], d[2]], levels)
+    with pytest.raises(ValueError):
+        res.getDetail(levels)
+    with pytest.raises(TypeError):
+        SWTResult(None, d, levels)

@@ -6,7 +6,7 @@ behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
 from .api import (BatchSIMDMODWT, BoundaryMode, IllegalStateException, InvalidArgumentException, InvalidSignalException, MODWTResult,
                   InvalidStateException, MODWTStreamingDenoiser, MODWTStreamingTransform, MODWTTransform, NoiseEstimation,
-                  StreamingStatistics,
+                  SparseSWTResult, StreamingStatistics, SWTResult,
                   MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult, ParallelMultiLevelMODWT,
                   ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
                   WaveletTransformException)
@@ -18,5 +18,5 @@ __all__ = [
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
     "WaveletDenoiser", "ThresholdMethod", "ThresholdType", "BatchSIMDMODWT", "ParallelMultiLevelMODWT",
     "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException", "MODWTStreamingTransform",
-    "InvalidStateException", "StreamingStatistics",
+    "InvalidStateException", "StreamingStatistics", "SWTResult", "SparseSWTResult",
 ]

@@ -103,6 +103,10 @@ SIGNATURES = {
                                                    _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32,
                                                    C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_double, _vp, _vp,
                                                    _vp, C.c_size_t, _vp]),
+    "vw_swt_sparsify_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp]),
+    "vw_swt_sparsify_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    "vw_swt_densify_batch": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp]),
+    "vw_swt_densify_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "vw_transpose": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
     "vw_transpose_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),

@@ -1208,6 +1208,146 @@ class MODWTStreamingTransform:
 
 
 # ---------------------------------------------------------------------------
+# swt/SWTResult.java
+# ---------------------------------------------------------------------------
+
+class SWTResult:
+    """Mirror of swt/SWTResult.java: immutable approximation + per-level details (level index 0-based, as in the
+    reference), lazily cached energies, and the sparse form whose compaction runs on the GPU."""
+
+    def __init__(self, approximation, details, levels, ctx: Optional[N.Context] = None):
+        # :43-60
+        if approximation is None:
+            raise TypeError("Approximation cannot be null")
+        if details is None:
+            raise TypeError("Details cannot be null")
+        if len(details) != levels:
+            raise ValueError("Details array length must match levels")
+        self._a = np.array(approximation, dtype=np.float64)
+        self._levels = int(levels)
+        self._n = int(self._a.size)
+        for d in details:
+            if d is None or len(d) != self._n:
+                raise ValueError("All detail levels must have same length as approximation")
+        self._d = np.array(details, dtype=np.float64).reshape(self._levels, self._n)
+        self._ctx = ctx
+        self._detail_energies = [None] * self._levels
+        self._total_energy = None
+
+    def getApproximation(self):
+        return self._a.copy()
+
+    def getDetail(self, level):
+        if level < 0 or level >= self._levels:
+            raise ValueError("Level must be between 0 and %d" % (self._levels - 1))
+        return self._d[level].copy()
+
+    def getAllDetails(self):
+        return self._d.copy()
+
+    def getLevels(self):
+        return self._levels
+
+    def getSignalLength(self):
+        return self._n
+
+    def getDetailEnergy(self, level):
+        # :124-147, summed in index order like the Java loop
+        if level < 0 or level >= self._levels:
+            raise ValueError("Level must be between 0 and %d" % (self._levels - 1))
+        if self._detail_energies[level] is None:
+            self._detail_energies[level] = MultiLevelMODWTResult._energy(self._d[level])
+        return self._detail_energies[level]
+
+    def getApproximationEnergy(self):
+        return MultiLevelMODWTResult._energy(self._a)
+
+    def getTotalEnergy(self):
+        if self._total_energy is None:
+            e = self.getApproximationEnergy()
+            for level in range(self._levels):
+                e += self.getDetailEnergy(level)
+            self._total_energy = e
+        return self._total_energy
+
+    def toSparse(self, threshold):
+        """:190-192"""
+        return SparseSWTResult(self, threshold)
+
+    def __eq__(self, other):
+        return (isinstance(other, SWTResult) and self._levels == other._levels and self._n == other._n
+                and _java_arrays_equal(self._a, other._a) and _java_arrays_equal(self._d, other._d))
+
+    def __hash__(self):
+        return hash((self._levels, self._n, self._a.tobytes(), self._d.tobytes()))
+
+    def __repr__(self):
+        return "SWTResult[levels=%d, signalLength=%d, totalEnergy=%.6f]" % (self._levels, self._n, self.getTotalEnergy())
+
+
+def _java_arrays_equal(a, b):
+    """Arrays.equals(double[], double[]): element-wise Double.doubleToLongBits equality (NaN equals NaN, 0.0 != -0.0)"""
+    if a.shape != b.shape:
+        return False
+    an, bn = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(an, bn) and np.array_equal(a[~an].view(np.uint64), b[~bn].view(np.uint64)))
+
+
+class SparseSWTResult:
+    """SWTResult.SparseSWTResult (:198-257): dense approximation, per-level (index, value) lists of the detail
+    entries with |v| > threshold.  The compaction (count pass, prefix sum, ordered fill) and the expansion back to
+    dense bands are GPU kernels."""
+
+    def __init__(self, full: SWTResult, threshold):
+        self._ctx = full._ctx if full._ctx is not None else N.default_context()
+        self._n, self._levels, self._threshold = full._n, full._levels, float(threshold)
+        self._a = full._a.copy()
+        ctx = self._ctx
+        block = np.empty((1, self._levels + 1, self._n))
+        block[0, :self._levels] = full._d
+        block[0, self._levels] = full._a
+        counts = np.zeros(self._levels, dtype=np.int64)
+        if self._n > 0:
+            _raise_for_status(ctx, ctx.lib.vw_swt_sparsify_batch(ctx.handle, _vp(block), 1, self._n, self._levels, self._threshold,
+                                                                 _vp(counts), None, None, None))
+        self._offsets = np.zeros(self._levels + 1, dtype=np.int64)
+        np.cumsum(counts, out=self._offsets[1:])
+        total = int(self._offsets[-1])
+        self._indices = np.empty(total, dtype=np.int32)
+        self._values = np.empty(total)
+        if total > 0:
+            _raise_for_status(ctx, ctx.lib.vw_swt_sparsify_batch(ctx.handle, _vp(block), 1, self._n, self._levels, self._threshold,
+                                                                 None, _vp(self._offsets), _vp(self._indices), _vp(self._values)))
+
+    def getNonZeroCount(self, level):
+        return int(self._offsets[level + 1] - self._offsets[level])
+
+    def getSparseDetail(self, level):
+        """(indices, values) of one level (not in the reference's public surface; for inspection and tests)"""
+        lo, hi = int(self._offsets[level]), int(self._offsets[level + 1])
+        return self._indices[lo:hi].copy(), self._values[lo:hi].copy()
+
+    def toFull(self):
+        """:225-231"""
+        ctx = self._ctx
+        block = np.empty((1, self._levels + 1, self._n))
+        block[0, self._levels] = self._a
+        if self._n > 0:
+            _raise_for_status(ctx, ctx.lib.vw_swt_densify_batch(ctx.handle, _vp(self._offsets), _vp(self._indices), _vp(self._values),
+                                                                1, self._n, self._levels, _vp(block)))
+        return SWTResult(self._a, block[0, :self._levels], self._levels, ctx)
+
+    def getCompressionRatio(self):
+        """:238-247"""
+        original = self._n * (self._levels + 1)
+        compressed = self._n + 2 * int(self._offsets[-1])
+        return original / compressed
+
+    def getThreshold(self):
+        return self._threshold
+
+
+# ---------------------------------------------------------------------------
 # modwt/BatchSIMDMODWT.java and modwt/ParallelMultiLevelMODWT.java
 # ---------------------------------------------------------------------------
 

@@ -1262,4 +1262,97 @@ __global__ void __launch_bounds__(kThreads) k_transpose(const double* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// sparse detail bands (swt/SWTResult.java toSparse / toFull)
+// ---------------------------------------------------------------------------
+//
+// One workgroup per detail band (row, level).  Pass 1 (indices == nullptr) counts the entries with
+// |v| > threshold; pass 2 writes them in index order at offsets[band]: every lane owns four consecutive
+// elements of a 1024-element chunk, a workgroup prefix sum of the lanes' counts gives each lane its place.
+
+struct SparsifyArgs {
+    const double* coeffs;  // band (r, j) at coeffs + r*row_stride + j*band_stride
+    int64_t row_stride, band_stride;
+    int64_t n;
+    int32_t levels;
+    double threshold;
+    int64_t* counts;         // [rows * levels] (pass 1)
+    const int64_t* offsets;  // [rows * levels] (pass 2)
+    int32_t* indices;        // pass 2
+    double* values;          // pass 2
+};
+
+__global__ void __launch_bounds__(kThreads) k_sparsify(const SparsifyArgs a) {
+    __shared__ unsigned wsum[4];
+    __shared__ unsigned long long red[kThreads];
+    const int tid = threadIdx.x;
+    const int64_t band = blockIdx.x;
+    const int64_t row = band / a.levels;
+    const int level = static_cast<int>(band - row * a.levels);
+    const double* __restrict__ c = a.coeffs + row * a.row_stride + static_cast<int64_t>(level) * a.band_stride;
+    const int64_t n = a.n;
+    if (a.indices == nullptr) {
+        unsigned long long cnt = 0;
+        for (int64_t i = tid; i < n; i += kThreads) cnt += fabs(c[i]) > a.threshold ? 1u : 0u;
+        red[tid] = cnt;
+        __syncthreads();
+        for (int s = kThreads / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) a.counts[band] = static_cast<int64_t>(red[0]);
+        return;
+    }
+    int64_t run = a.offsets[band];
+    for (int64_t base = 0; base < n; base += 4 * kThreads) {
+        const int64_t i0 = base + 4 * tid;
+        double v[4];
+        bool keep[4];
+        unsigned mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (i0 + k < n) ? c[i0 + k] : 0.0;
+            keep[k] = (i0 + k < n) && fabs(v[k]) > a.threshold;
+            mine += keep[k] ? 1u : 0u;
+        }
+        unsigned inc = wave_inclusive_scan(mine);
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < (tid >> 6)) before += wsum[w];
+            total += wsum[w];
+        }
+        int64_t pos = run + before + (inc - mine);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (keep[k]) {
+                a.indices[pos] = static_cast<int32_t>(i0 + k);
+                a.values[pos] = v[k];
+                ++pos;
+            }
+        run += total;
+        __syncthreads();
+    }
+}
+
+struct DensifyArgs {
+    const int64_t* offsets;  // [bands + 1]
+    const int32_t* indices;
+    const double* values;
+    double* out;             // band b at out + (b / levels)*row_stride + (b % levels)*band_stride, zeroed beforehand
+    int64_t row_stride, band_stride;
+    int32_t levels;
+};
+
+__global__ void __launch_bounds__(kThreads) k_densify(const DensifyArgs a) {
+    const int64_t band = blockIdx.x;
+    const int64_t row = band / a.levels;
+    const int level = static_cast<int>(band - row * a.levels);
+    double* out = a.out + row * a.row_stride + static_cast<int64_t>(level) * a.band_stride;
+    const int64_t e0 = a.offsets[band], e1 = a.offsets[band + 1];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kThreads) out[a.indices[e]] = a.values[e];
+}
+
 }  // namespace vw

@@ -1712,6 +1712,160 @@ extern "C" int32_t vw_streaming_denoise_batch(vw_ctx* ctx, vw_stream_state* stat
 }
 
 // ---------------------------------------------------------------------------
+// sparse detail bands (SWTResult.toSparse / SparseSWTResult.toFull)
+// ---------------------------------------------------------------------------
+
+static int sparse_checks(vw_ctx* ctx, const void* p0, int64_t b, int64_t n, int levels) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (b < 0 || n < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative size");
+    if (levels < 1 || levels > kMaxLevels) return set_err(ctx, VW_E_LEVEL, "Invalid number of levels %d", levels);
+    if (n > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "indices are 32-bit: signals of more than 2^31-1 samples are not supported");
+    if (b * levels > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    if (b > 0 && p0 == nullptr) return set_err(ctx, VW_E_NULL, "Details cannot be null");
+    return VW_OK;
+}
+
+extern "C" int32_t vw_swt_sparsify_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n, int32_t levels,
+                                             double threshold, int64_t* counts_dev, const int64_t* offsets_dev,
+                                             int32_t* indices_dev, double* values_dev, void* stream) {
+    int rc = sparse_checks(ctx, coeffs_dev, b, n, levels);
+    if (rc != VW_OK) return rc;
+    if (b == 0 || n == 0) return VW_OK;
+    if (indices_dev == nullptr && counts_dev == nullptr) return set_err(ctx, VW_E_NULL, "counts cannot be null in the counting pass");
+    if (indices_dev != nullptr && (offsets_dev == nullptr || values_dev == nullptr))
+        return set_err(ctx, VW_E_NULL, "offsets and values cannot be null in the fill pass");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    SparsifyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.coeffs = coeffs_dev;
+    a.row_stride = static_cast<int64_t>(levels + 1) * n;
+    a.band_stride = n;
+    a.n = n;
+    a.levels = levels;
+    a.threshold = threshold;
+    a.counts = counts_dev;
+    a.offsets = offsets_dev;
+    a.indices = indices_dev;
+    a.values = values_dev;
+    hipLaunchKernelGGL(k_sparsify, dim3(static_cast<unsigned>(b * levels)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_swt_sparsify_batch(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int32_t levels, double threshold,
+                                         int64_t* counts, const int64_t* offsets, int32_t* indices, double* values) {
+    int rc = sparse_checks(ctx, coeffs, b, n, levels);
+    if (rc != VW_OK) return rc;
+    if (b == 0 || n == 0) return VW_OK;
+    if (indices == nullptr && counts == nullptr) return set_err(ctx, VW_E_NULL, "counts cannot be null in the counting pass");
+    if (indices != nullptr && (offsets == nullptr || values == nullptr))
+        return set_err(ctx, VW_E_NULL, "offsets and values cannot be null in the fill pass");
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t bands = b * levels;
+    const size_t cbytes = static_cast<size_t>(b) * (levels + 1) * n * 8;
+    rc = ensure(ctx, ctx->stage_in, cbytes);
+    if (rc != VW_OK) return rc;
+    double* dc = static_cast<double*>(ctx->stage_in.p);
+    VW_HIP(ctx, hipMemcpyAsync(dc, coeffs, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (indices == nullptr) {
+        rc = ensure(ctx, ctx->stage_out, static_cast<size_t>(bands) * 8);
+        if (rc != VW_OK) return rc;
+        int64_t* dcnt = static_cast<int64_t*>(ctx->stage_out.p);
+        rc = vw_swt_sparsify_batch_dev(ctx, dc, b, n, levels, threshold, dcnt, nullptr, nullptr, nullptr, ctx->stream);
+        if (rc != VW_OK) return rc;
+        VW_HIP(ctx, hipMemcpyAsync(counts, dcnt, static_cast<size_t>(bands) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return VW_OK;
+    }
+    const int64_t total = offsets[bands];  // the caller's prefix sum ends with the number of entries
+    if (total < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative entry count");
+    const size_t obytes = round256(static_cast<size_t>(bands) * 8);
+    const size_t ibytes = round256(static_cast<size_t>(total) * 4);
+    rc = ensure(ctx, ctx->stage_out, obytes + ibytes + static_cast<size_t>(total) * 8 + 256);
+    if (rc != VW_OK) return rc;
+    char* base = static_cast<char*>(ctx->stage_out.p);
+    int64_t* doff = reinterpret_cast<int64_t*>(base);
+    int32_t* didx = reinterpret_cast<int32_t*>(base + obytes);
+    double* dval = reinterpret_cast<double*>(base + obytes + ibytes);
+    VW_HIP(ctx, hipMemcpyAsync(doff, offsets, static_cast<size_t>(bands) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_swt_sparsify_batch_dev(ctx, dc, b, n, levels, threshold, nullptr, doff, didx, dval, ctx->stream);
+    if (rc != VW_OK) return rc;
+    if (total > 0) {
+        VW_HIP(ctx, hipMemcpyAsync(indices, didx, static_cast<size_t>(total) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VW_HIP(ctx, hipMemcpyAsync(values, dval, static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+extern "C" int32_t vw_swt_densify_batch_dev(vw_ctx* ctx, const int64_t* offsets_dev, const int32_t* indices_dev,
+                                            const double* values_dev, int64_t b, int64_t n, int32_t levels,
+                                            double* coeffs_out_dev, void* stream) {
+    int rc = sparse_checks(ctx, coeffs_out_dev, b, n, levels);
+    if (rc != VW_OK) return rc;
+    if (b == 0 || n == 0) return VW_OK;
+    if (offsets_dev == nullptr) return set_err(ctx, VW_E_NULL, "offsets cannot be null");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
+    // the detail bands of a row are contiguous: one 2-D memset clears them and leaves the approximation bands alone
+    VW_HIP(ctx, hipMemset2DAsync(coeffs_out_dev, static_cast<size_t>(rowc) * 8, 0, static_cast<size_t>(levels) * n * 8,
+                                 static_cast<size_t>(b), s));
+    DensifyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.offsets = offsets_dev;
+    a.indices = indices_dev;
+    a.values = values_dev;
+    a.out = coeffs_out_dev;
+    a.row_stride = rowc;
+    a.band_stride = n;
+    a.levels = levels;
+    hipLaunchKernelGGL(k_densify, dim3(static_cast<unsigned>(b * levels)), dim3(kThreads), 0, s, a);
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
+extern "C" int32_t vw_swt_densify_batch(vw_ctx* ctx, const int64_t* offsets, const int32_t* indices, const double* values,
+                                        int64_t b, int64_t n, int32_t levels, double* coeffs_out) {
+    int rc = sparse_checks(ctx, coeffs_out, b, n, levels);
+    if (rc != VW_OK) return rc;
+    if (b == 0 || n == 0) return VW_OK;
+    if (offsets == nullptr) return set_err(ctx, VW_E_NULL, "offsets cannot be null");
+    std::lock_guard<std::recursive_mutex> hold(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t bands = b * levels;
+    const int64_t total = offsets[bands];
+    if (total < 0 || (total > 0 && (indices == nullptr || values == nullptr)))
+        return set_err(ctx, VW_E_NULL, "indices and values cannot be null");
+    const size_t cbytes = static_cast<size_t>(b) * (levels + 1) * n * 8;
+    const size_t obytes = round256(static_cast<size_t>(bands + 1) * 8);
+    const size_t ibytes = round256(static_cast<size_t>(total) * 4);
+    rc = ensure(ctx, ctx->stage_out, cbytes);
+    if (rc == VW_OK) rc = ensure(ctx, ctx->stage_in, obytes + ibytes + static_cast<size_t>(total) * 8 + 256);
+    if (rc != VW_OK) return rc;
+    char* base = static_cast<char*>(ctx->stage_in.p);
+    int64_t* doff = reinterpret_cast<int64_t*>(base);
+    int32_t* didx = reinterpret_cast<int32_t*>(base + obytes);
+    double* dval = reinterpret_cast<double*>(base + obytes + ibytes);
+    double* dout = static_cast<double*>(ctx->stage_out.p);
+    VW_HIP(ctx, hipMemcpyAsync(doff, offsets, static_cast<size_t>(bands + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (total > 0) {
+        VW_HIP(ctx, hipMemcpyAsync(didx, indices, static_cast<size_t>(total) * 4, hipMemcpyHostToDevice, ctx->stream));
+        VW_HIP(ctx, hipMemcpyAsync(dval, values, static_cast<size_t>(total) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = vw_swt_densify_batch_dev(ctx, doff, didx, dval, b, n, levels, dout, ctx->stream);
+    if (rc != VW_OK) return rc;
+    // only the detail bands come back: the caller's approximation bands stay as they are
+    VW_HIP(ctx, hipMemcpy2DAsync(coeffs_out, static_cast<size_t>(levels + 1) * n * 8, dout, static_cast<size_t>(levels + 1) * n * 8,
+                                 static_cast<size_t>(levels) * n * 8, static_cast<size_t>(b), hipMemcpyDeviceToHost, ctx->stream));
+    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VW_OK;
+}
+
+// ---------------------------------------------------------------------------
 // structure-of-arrays batch + layout conversion
 // ---------------------------------------------------------------------------
 
