@@ -341,6 +341,13 @@ static void sdry_runs(int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, i
     *nseg_out = static_cast<int32_t>((tiles + nch - 1) / nch);
 }
 
+// Launches that move more than 1 GiB (four times the last-level cache) store their results with the streaming
+// hint; smaller ones leave them cacheable for the kernel that reads them next.  VW_NT_STORES=0/1 overrides.
+static int streaming_stores(int64_t b, int64_t n, int levels) {
+    if (const char* e = getenv("VW_NT_STORES")) return atoi(e) != 0;
+    return static_cast<double>(b) * static_cast<double>(n) * 8.0 * (levels + 2) > 1073741824.0;
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---------------------------------------------------------------------------
@@ -492,6 +499,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             sdry_runs(b, tiles, st.ndry, &a.nchunks, &a.ntiles);
             a.first_bad = first ? first_bad_cell : nullptr;
             a.taps = taps;
+            a.nt_store = streaming_stores(b, n, levels);
             if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
@@ -540,6 +548,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             }
             a.first_bad = first ? first_bad_cell : nullptr;
             a.taps = taps;
+            a.nt_store = streaming_stores(b, n, levels);
             const bool vec2 = (n % 2 == 0) && (in_stride % 2 == 0) && (vstride % 2 == 0) && aligned16(in) &&
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
@@ -777,6 +786,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
+            a.nt_store = streaming_stores(b, n, levels);
             if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = 0;
@@ -821,6 +831,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
+            a.nt_store = streaming_stores(b, n, levels);
             if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
                 if (strstr(dbg, "nostore")) a.n_store = 0;
                 if (strstr(dbg, "nocompute")) a.lh = 0;

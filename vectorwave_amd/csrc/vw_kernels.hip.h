@@ -58,6 +58,7 @@ struct FwdArgs {
     int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     int32_t ndry, hist_cap;  // k_fwd_sdry: warm-up tiles per run, doubles of history storage
     unsigned long long* first_bad;   // nullptr = no finite check
+    int32_t nt_store;      // results are stored with the streaming hint (launches far larger than the caches)
     Taps taps;
 };
 
@@ -86,6 +87,7 @@ struct InvArgs {
     int64_t thr_row_stride, thr_level_stride;
     unsigned long long* first_bad;  // flat index into the coefficient block of the first NaN/Inf
     int32_t check_rin;     // rin is the a_J band of the block (top group): include it in the check
+    int32_t nt_store;      // results are stored with the streaming hint (launches far larger than the caches)
     Taps taps;
 };
 
@@ -109,6 +111,21 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblk) {
 // prefetch load) issued so far -- here those must stay in flight across the
 // per-level barriers.  LDS is coherent within the CU, so "my LDS operations have
 // completed" + s_barrier is all the tile hand-off between waves needs.
+// 16-byte global store of a result that this kernel never reads back.  nt: the launch writes far more than
+// the last-level caches hold, so the lines are marked streaming (measured on 69 GB launches: the inverse's
+// memory-only time drops 5 %); small launches keep their results cacheable for the kernel that reads them next.
+typedef double vw_f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gstore2(double* p, double2 v, int nt) {
+    if (nt) {
+        vw_f64x2 x;
+        x.x = v.x;
+        x.y = v.y;
+        __builtin_nontemporal_store(x, reinterpret_cast<vw_f64x2*>(p));
+    } else {
+        *reinterpret_cast<double2*>(p) = v;
+    }
+}
+
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -376,7 +393,7 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
         for (int k = 0; k < PPT; ++k) {
             const int64_t t = t0 + k * kChunk + 2 * tid;
             if (VEC2) {
-                if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                if (t < ns) gstore2(wrow + t, make_double2(aw[k][0], aw[k][1]), a.nt_store);
             } else {
                 if (t < ns) wrow[t] = aw[k][0];
                 if (t + 1 < ns) wrow[t + 1] = aw[k][1];
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(kThreads) k_fwd_fused(const FwdArgs a) {
             for (int k = 0; k < PPT; ++k) {
                 const int64_t t = t0 + k * kChunk + 2 * tid;
                 if (VEC2) {
-                    if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                    if (t < ns) gstore2(vrow + t, make_double2(av[k][0], av[k][1]), a.nt_store);
                 } else {
                     if (t < ns) vrow[t] = av[k][0];
                     if (t + 1 < ns) vrow[t + 1] = av[k][1];
@@ -562,7 +579,7 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
             for (int k = 0; k < PPT; ++k) {
                 const int64_t t = t0 + k * CH + 2 * tid;
                 if (VEC2) {
-                    if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                    if (t < ns) gstore2(wrow + t, make_double2(aw[k][0], aw[k][1]), a.nt_store);
                 } else {
                     if (t < ns) wrow[t] = aw[k][0];
                     if (t + 1 < ns) wrow[t + 1] = aw[k][1];
@@ -574,7 +591,7 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
                 for (int k = 0; k < PPT; ++k) {
                     const int64_t t = t0 + k * CH + 2 * tid;
                     if (VEC2) {
-                        if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                        if (t < ns) gstore2(vrow + t, make_double2(av[k][0], av[k][1]), a.nt_store);
                     } else {
                         if (t < ns) vrow[t] = av[k][0];
                         if (t + 1 < ns) vrow[t + 1] = av[k][1];
@@ -729,7 +746,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
                 for (int k = 0; k < PPT; ++k) {
                     const int64_t t = t0 + k * CH + 2 * tid;
                     if (VEC2) {
-                        if (t < ns) *reinterpret_cast<double2*>(wrow + t) = make_double2(aw[k][0], aw[k][1]);
+                        if (t < ns) gstore2(wrow + t, make_double2(aw[k][0], aw[k][1]), a.nt_store);
                     } else {
                         if (t < ns) wrow[t] = aw[k][0];
                         if (t + 1 < ns) wrow[t + 1] = aw[k][1];
@@ -743,7 +760,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
                     for (int k = 0; k < PPT; ++k) {
                         const int64_t t = t0 + k * CH + 2 * tid;
                         if (VEC2) {
-                            if (t < ns) *reinterpret_cast<double2*>(vrow + t) = make_double2(av[k][0], av[k][1]);
+                            if (t < ns) gstore2(vrow + t, make_double2(av[k][0], av[k][1]), a.nt_store);
                         } else {
                             if (t < ns) vrow[t] = av[k][0];
                             if (t + 1 < ns) vrow[t + 1] = av[k][1];
@@ -961,7 +978,7 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
             for (int k = 0; k < PPT; ++k) {
                 const int64_t t = t0 + k * kChunk + 2 * tid;
                 if (VEC2) {
-                    if (t < a.n_store) *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
+                    if (t < a.n_store) gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
                 } else {
                     if (t < a.n_store) orow[t] = acc[k][0];
                     if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
@@ -1151,7 +1168,7 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
                         const int64_t t = t0 + k * CH + 2 * tid;
                         if (VEC2) {
                             if (t < a.n_store)
-                                *reinterpret_cast<double2*>(orow + t) = make_double2(acc[k][0], acc[k][1]);
+                                gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
                         } else {
                             if (t < a.n_store) orow[t] = acc[k][0];
                             if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
