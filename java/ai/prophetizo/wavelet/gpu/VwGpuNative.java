@@ -93,6 +93,13 @@ public final class VwGpuNative {
     // int32 vw_transpose(ctx, in, rows, cols, out)
     static final MethodHandle VW_TRANSPOSE = h("vw_transpose",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+    // int32 vw_swt_sparsify_batch(ctx, coeffs, b, n, levels, threshold, counts, offsets, indices, values)
+    static final MethodHandle VW_SWT_SPARSIFY = h("vw_swt_sparsify_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_DOUBLE, ADDRESS, ADDRESS, ADDRESS,
+            ADDRESS));
+    // int32 vw_swt_densify_batch(ctx, offsets, indices, values, b, n, levels, coeffs_out)
+    static final MethodHandle VW_SWT_DENSIFY = h("vw_swt_densify_batch",
+        FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, ADDRESS));
     // int32 vw_swt_universal_threshold_batch(ctx, coeffs, b, n, levels, sqrt_2_ln_n, thresholds)
     static final MethodHandle VW_UNIVERSAL_THRESHOLD = h("vw_swt_universal_threshold_batch",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_DOUBLE, ADDRESS));
