@@ -294,6 +294,21 @@ class StreamingTransformState:
             pass
 
 
+def stream_multilevel(data, wavelet, buffer_size, levels, boundary=PERIODIC, flush=True):
+    """MultiLevelMODWTStreamingTransform over a whole stream: blocks [k][levels+1][bufferSize] (d_1..d_J, a_J)."""
+    d = _f64(data)
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    cap = d.size // buffer_size + 1
+    out = np.empty((cap, levels + 1, buffer_size))
+    f = lib().vwo_stream_multilevel
+    f.restype = C.c_int64
+    nb = f(_p(d), C.c_int64(d.size), C.c_int64(buffer_size), C.c_int(levels), _p(h), C.c_int(h.size), _p(g), C.c_int(g.size),
+           C.c_int(boundary), C.c_int(1 if flush else 0), _p(out), C.c_int64(cap))
+    if nb < 0:
+        return int(-nb), None
+    return 0, out[:nb].copy()
+
+
 def sparse_vector(dense, threshold):
     """SWTResult.SparseVector (swt/SWTResult.java:267-290): (indices int32, values) of |v| > threshold."""
     d = _f64(dense)

@@ -871,6 +871,46 @@ int vwo_stream_xform_flush(vwo_stream_xform *s, const double *h, int lh, const d
     return 1;
 }
 
+/* modwt/streaming/MultiLevelMODWTStreamingTransform.java:112-196: non-overlapping blocks of bufferSize
+ * samples, each decomposed to `levels` levels; with flush != 0 the unconsumed samples, zero-padded, make a last
+ * block (:166-196).  The whole stream is given at once and walked sample by sample through the ring buffer of
+ * the reference.  Blocks go to out[block][levels+1][bufferSize] (d_1..d_J, a_J; the reference publishes the
+ * levels of a block one by one, the approximation with the last).  Returns the number of blocks, or -status. */
+int64_t vwo_stream_multilevel(const double *data, int64_t len, int64_t buffer_size, int levels, const double *h,
+                              int lh, const double *g, int lg, int boundary, int flush, double *out,
+                              int64_t max_blocks) {
+    double *ring = (double *)calloc((size_t)buffer_size, sizeof(double));
+    double *buf = (double *)malloc(sizeof(double) * (size_t)buffer_size);
+    int64_t pos = 0, count = 0, blocks = 0;
+    int status = 0;
+    for (int64_t t = 0; t < len && status == 0; t++) {
+        ring[pos] = data[t];
+        pos = (pos + 1) % buffer_size;
+        count++;
+        if (count >= buffer_size) {
+            int64_t start = (pos - buffer_size + buffer_size) % buffer_size;
+            for (int64_t i = 0; i < buffer_size; i++) buf[i] = ring[(start + i) % buffer_size];
+            if (blocks < max_blocks)
+                status = vwo_multilevel_decompose(buf, buffer_size, levels, h, lh, g, lg, boundary,
+                                                  out + blocks * (levels + 1) * buffer_size);
+            blocks++;
+            count = 0;
+        }
+    }
+    if (flush && count > 0 && status == 0) {
+        memset(buf, 0, sizeof(double) * (size_t)buffer_size);
+        int64_t start = (pos - count + buffer_size) % buffer_size;
+        for (int64_t i = 0; i < count; i++) buf[i] = ring[(start + i) % buffer_size];
+        if (blocks < max_blocks)
+            status = vwo_multilevel_decompose(buf, buffer_size, levels, h, lh, g, lg, boundary,
+                                              out + blocks * (levels + 1) * buffer_size);
+        blocks++;
+    }
+    free(ring);
+    free(buf);
+    return status != 0 ? -(int64_t)status : blocks;
+}
+
 /* ------------------------------------------------------------------------ */
 /* swt/SWTResult.java: sparse detail bands */
 /* ------------------------------------------------------------------------ */

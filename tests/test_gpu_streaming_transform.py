@@ -110,3 +110,56 @@ def test_argument_checks(ctx):
         t.process(np.zeros(0))
     with pytest.raises(InvalidSignalException):
         t.process(np.full(300, np.nan))
+
+
+@pytest.mark.parametrize("mode", [P, Z, S])
+@pytest.mark.parametrize("wn,bsz,levels", [("haar", 16, 3), ("db4", 64, 3), ("db4", 480, 4), ("sym8", 1000, 5)])
+def test_multilevel_streaming_blocks(ctx, wn, bsz, levels, mode):
+    w = get_wavelet(wn)
+    rng = np.random.default_rng(bsz + levels)
+    data = rng.standard_normal(5 * bsz + 7)
+    st, want = o.stream_multilevel(data, w, bsz, levels, mode)
+    assert st == 0
+    sink = _Collector()
+    t = MODWTStreamingTransform.createMultiLevel(w, BoundaryMode(mode), bsz, levels, ctx=ctx)
+    t.subscribe(sink)
+    t.process(data[:3])
+    t.process(data[3:2 * bsz + 1])
+    t.processSample(data[2 * bsz + 1])
+    t.process(data[2 * bsz + 2:])
+    assert t.getBufferLevel() == 7 and t.getStatistics().getBlocksProcessed() == 5
+    t.close()
+    assert sink.completed and len(sink.items) == 6 * levels
+    for blk in range(6):
+        for level in range(1, levels + 1):
+            item = sink.items[blk * levels + level - 1]
+            assert_bits_equal(item.detailCoeffs(), want[blk, level - 1], "block %d level %d" % (blk, level))
+            if level == levels:
+                assert_bits_equal(item.approximationCoeffs(), want[blk, levels], "block %d approximation" % blk)
+            else:
+                assert item.approximationCoeffs().size == 0  # :247-249
+    with pytest.raises(InvalidStateException):
+        t.process(np.zeros(4))
+
+
+def test_multilevel_streaming_lockstep_and_errors(ctx):
+    w = get_wavelet("db4")
+    streams, bsz, levels = 4, 128, 3
+    data = np.random.default_rng(11).standard_normal((streams, 300))
+    got = []
+    with MODWTStreamingTransform.createMultiLevel(w, BoundaryMode.PERIODIC, bsz, levels, streams=streams, ctx=ctx) as t:
+        t.subscribe(got.append)
+        t.process(data)
+    got = np.array(got)  # [blocks][streams][levels+1][bsz]
+    for s in range(streams):
+        st, want = o.stream_multilevel(data[s], w, bsz, levels)
+        assert_bits_equal(got[:, s], want, "stream %d" % s)
+    for bad in (lambda: MODWTStreamingTransform.createMultiLevel(None, BoundaryMode.PERIODIC, 64, 2),
+                lambda: MODWTStreamingTransform.createMultiLevel("db4", None, 64, 2),
+                lambda: MODWTStreamingTransform.createMultiLevel("db4", BoundaryMode.PERIODIC, 0, 2),
+                lambda: MODWTStreamingTransform.createMultiLevel("db4", BoundaryMode.PERIODIC, 64, 0)):
+        with pytest.raises(InvalidArgumentException):
+            bad()
+    t = MODWTStreamingTransform.createMultiLevel("db4", BoundaryMode.PERIODIC, 16, 5, ctx=ctx)
+    with pytest.raises(InvalidArgumentException):  # five levels do not fit a 16-sample block
+        t.process(np.zeros(16))

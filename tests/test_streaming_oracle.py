@@ -236,3 +236,23 @@ def test_streaming_transform_windows(wn, bsz):
         padded[:level] = data[data.size - level:]
         assert np.array_equal(tail, o.modwt_forward_batch(padded[None], wv))
     assert st.level() == 0 and st.flush().shape[0] == 0
+
+
+# ---- modwt/streaming/MultiLevelMODWTStreamingTransform.java ---------------------------------------------------
+
+@pytest.mark.parametrize("wn,bsz,levels", [("haar", 16, 3), ("db4", 64, 3), ("db4", 256, 5), ("sym8", 100, 2)])
+def test_multilevel_streaming_blocks(wn, bsz, levels):
+    wv = get_wavelet(wn)
+    rng = np.random.default_rng(bsz)
+    data = rng.standard_normal(3 * bsz + 5)
+    st, got = o.stream_multilevel(data, wv, bsz, levels)
+    assert st == 0 and got.shape == (4, levels + 1, bsz)
+    tail = np.zeros(bsz)
+    tail[:5] = data[3 * bsz:]
+    blocks = np.concatenate([data[:3 * bsz].reshape(3, bsz), tail[None]])  # :138-146 and :166-176: no overlap, zero-padded tail
+    st, want = o.decompose_batch(blocks, wv, levels)
+    assert st == 0 and np.array_equal(got, want)
+    st, got = o.stream_multilevel(data, wv, bsz, levels, flush=False)
+    assert got.shape[0] == 3
+    # more levels than the block length allows: the reference's decompose throws
+    assert o.stream_multilevel(data[:40], get_wavelet("db4"), 16, 5)[0] != 0

@@ -5,7 +5,7 @@ VectorWaveSwtAdapter API over libvwgpu.so (hand-written gfx950 HIP kernels
 behind the C ABI in include/vwgpu.h).  There is no CPU compute path.
 """
 from .api import (BatchSIMDMODWT, BoundaryMode, IllegalStateException, InvalidArgumentException, InvalidSignalException, MODWTResult,
-                  InvalidStateException, MODWTStreamingDenoiser, MODWTStreamingTransform, MODWTTransform, NoiseEstimation,
+                  InvalidStateException, MODWTStreamingDenoiser, MODWTStreamingTransform, MODWTTransform, MultiLevelMODWTStreamingTransform, NoiseEstimation,
                   SparseSWTResult, StreamingStatistics, SWTResult,
                   MultiLevelMODWTResult, MultiLevelMODWTTransform, MutableMultiLevelMODWTResult, ParallelMultiLevelMODWT,
                   ThresholdMethod, ThresholdType, VectorWaveSwtAdapter, WaveletDenoiser, WaveletOperations,
@@ -17,6 +17,6 @@ __all__ = [
     "MultiLevelMODWTResult", "MultiLevelMODWTTransform", "MutableMultiLevelMODWTResult", "VectorWaveSwtAdapter",
     "WaveletOperations", "WaveletTransformException", "Wavelet", "available_wavelets", "get_wavelet",
     "WaveletDenoiser", "ThresholdMethod", "ThresholdType", "BatchSIMDMODWT", "ParallelMultiLevelMODWT",
-    "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException", "MODWTStreamingTransform",
+    "MODWTStreamingDenoiser", "NoiseEstimation", "IllegalStateException", "MODWTStreamingTransform", "MultiLevelMODWTStreamingTransform",
     "InvalidStateException", "StreamingStatistics", "SWTResult", "SparseSWTResult",
 ]

@@ -1066,6 +1066,11 @@ class MODWTStreamingTransform:
         """MODWTStreamingTransform.create (:66-81)"""
         return MODWTStreamingTransform(wavelet, boundaryMode, bufferSize, streams, ctx)
 
+    @staticmethod
+    def createMultiLevel(wavelet, boundaryMode, bufferSize, levels, streams=1, ctx: Optional[N.Context] = None):
+        """MODWTStreamingTransform.createMultiLevel (:92-95)"""
+        return MultiLevelMODWTStreamingTransform(wavelet, boundaryMode, bufferSize, levels, streams, ctx)
+
     def __init__(self, wavelet, boundaryMode, bufferSize, streams=1, ctx: Optional[N.Context] = None):
         # MODWTStreamingTransformImpl.java:79-143
         if wavelet is None:
@@ -1205,6 +1210,84 @@ class MODWTStreamingTransform:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class MultiLevelMODWTStreamingTransform(MODWTStreamingTransform):
+    """Mirror of modwt/streaming/MultiLevelMODWTStreamingTransform.java: non-overlapping blocks of bufferSize
+    samples, each decomposed to `levels` levels.  Per block the reference publishes one MODWTResult per level
+    (details of that level; the approximation with the last level, an empty array before it, :146-152); the blocks
+    that one process() call completes are decomposed in ONE GPU batch.  With `streams` > 1 each published item is
+    the coefficient block [streams][levels+1][bufferSize] of one window instead."""
+
+    def __init__(self, wavelet, boundaryMode, bufferSize, levels, streams=1, ctx: Optional[N.Context] = None):
+        # :60-91
+        if wavelet is None:
+            raise InvalidArgumentException("Wavelet cannot be null")
+        if boundaryMode is None:
+            raise InvalidArgumentException("Boundary mode cannot be null")
+        if bufferSize <= 0:
+            raise InvalidArgumentException("Buffer size must be positive, got: %d" % bufferSize)
+        if levels < 1:
+            raise InvalidArgumentException("Levels must be at least 1, got: %d" % levels)
+        if streams <= 0:
+            raise InvalidArgumentException("Stream count must be positive")
+        self.wavelet = _as_wavelet(wavelet)
+        self.boundaryMode = BoundaryMode(boundaryMode)
+        self.bufferSize = int(bufferSize)
+        self.levels = int(levels)
+        self.streams = int(streams)
+        self.filterLength = len(self.wavelet.dec_lo)
+        self.overlapSize = 0  # blocks do not overlap here (:161 resets the sample count to zero)
+        self._ml = MultiLevelMODWTTransform(self.wavelet, self.boundaryMode, ctx)
+        self._pending = np.empty((self.streams, 0))
+        self._closed = False
+        self._subscribers = []
+        self._statistics = StreamingStatistics()
+
+    def _submit(self, blocks):
+        # blocks [streams][k][levels+1][bufferSize]
+        empty = np.empty(0)
+        for w in range(blocks.shape[1]):
+            if self.streams == 1:
+                items = [_LevelResult(blocks[0, w, self.levels] if level == self.levels else empty, blocks[0, w, level - 1])
+                         for level in range(1, self.levels + 1)]
+            else:
+                items = [blocks[:, w].copy()]
+            for item in items:
+                for s in self._subscribers:
+                    (s.onNext if hasattr(s, "onNext") else s)(item)
+
+    def _transform_windows(self, windows):
+        import time
+        t0 = time.perf_counter_ns()
+        k = windows.shape[1]
+        rows = np.ascontiguousarray(windows).reshape(self.streams * k, self.bufferSize)
+        coeffs = self._ml.decompose_block(rows, self.levels, True).reshape(self.streams, k, self.levels + 1, self.bufferSize)
+        self._submit(coeffs)
+        self._statistics._record_blocks(k, time.perf_counter_ns() - t0)
+
+    def flush(self):
+        """:166-196 (no closed check in the reference)"""
+        self._drain()
+
+
+class _LevelResult:
+    """MultiLevelMODWTStreamingTransform.MODWTResultWrapper (:262-310): one level of one block"""
+
+    def __init__(self, approx, details):
+        self._a, self._d = np.array(approx, dtype=np.float64), np.array(details, dtype=np.float64)
+
+    def approximationCoeffs(self):
+        return self._a.copy()
+
+    def detailCoeffs(self):
+        return self._d.copy()
+
+    def getSignalLength(self):
+        return int(self._a.size)
+
+    def isValid(self):
+        return bool(np.isfinite(self._a).all() and np.isfinite(self._d).all())
 
 
 # ---------------------------------------------------------------------------
