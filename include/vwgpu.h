@@ -119,6 +119,13 @@ int32_t vw_synchronize(vw_ctx *ctx);
 /* Number of HIP devices visible to the process (0 if none / no runtime). */
 int32_t vw_device_count(void);
 
+/* Page-locked host memory for the HOST-pointer entry points.  They accept any host memory, but copies to and
+ * from pageable memory go through the runtime's bounce buffers at a fraction of the PCIe rate; buffers obtained
+ * here are copied by DMA directly.  (No counterpart in the reference: a Java caller wraps the address in a
+ * MemorySegment of `bytes` bytes instead of allocating from an Arena.) */
+int32_t vw_host_alloc(vw_ctx *ctx, size_t bytes, void **out);
+int32_t vw_host_free(vw_ctx *ctx, void *ptr);
+
 /* ---- pure host helpers ------------------------------------------------- */
 
 /* MultiLevelMODWTTransform.calculateMaxLevels / getMaximumLevels

@@ -114,6 +114,39 @@ public final class VwGpuNative {
     static final MethodHandle VW_FIRST_NON_FINITE = h("vw_first_non_finite",
         FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
 
+    // int32 vw_host_alloc(ctx, bytes, out) / vw_host_free(ctx, ptr): page-locked host buffers (DMA at the PCIe rate)
+    static final MethodHandle VW_HOST_ALLOC = h("vw_host_alloc", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS));
+    static final MethodHandle VW_HOST_FREE = h("vw_host_free", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+
+    /** A page-locked off-heap segment of {@code bytes} bytes; release it with {@link #hostFree}. */
+    public static MemorySegment hostAlloc(MemorySegment ctx, long bytes) {
+        try (Arena a = Arena.ofConfined()) {
+            MemorySegment out = a.allocate(ADDRESS);
+            int st = (int) VW_HOST_ALLOC.invokeExact(ctx, bytes, out);
+            if (st != VW_OK) {
+                throw new OutOfMemoryError(lastError(ctx));
+            }
+            return out.get(ADDRESS, 0).reinterpret(bytes);
+        } catch (RuntimeException | Error e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    public static void hostFree(MemorySegment ctx, MemorySegment segment) {
+        try {
+            int st = (int) VW_HOST_FREE.invokeExact(ctx, segment);
+            if (st != VW_OK) {
+                throw new IllegalStateException(lastError(ctx));
+            }
+        } catch (RuntimeException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
     private VwGpuNative() {}
 
     /** Opens a context on a HIP device; the returned segment is the opaque vw_ctx*. */

@@ -224,3 +224,26 @@ def test_result_containers(ctx):
         MODWTResult.create([1.0, np.nan], [0.0, 0.0])
     with pytest.raises(ValueError):
         MODWTResult.create([1.0], [0.0, 0.0])
+
+
+@pytest.mark.gpu
+def test_page_locked_host_buffers(ctx):
+    """vw_host_alloc / vw_host_free: the host-pointer entry points give the same bits from page-locked buffers"""
+    import ctypes as C
+    from oracle import oracle as o
+    from vectorwave_amd import _native as N
+    from vectorwave_amd.wavelets import get_wavelet
+    from util import assert_bits_equal, gpu_forward, signals
+    x = signals(5, 1000, seed=3)
+    xp = ctx.host_array((5, 1000))
+    xp[:] = x
+    st, got, _ = gpu_forward(ctx, xp, "db4", 3, 0)
+    st2, want = o.decompose_batch(x, get_wavelet("db4"), 3, 0)
+    assert st == 0 and st2 == 0
+    assert_bits_equal(got, want, "forward from a page-locked buffer")
+    assert ctx.host_array((0, 4)).size == 0
+    ptr = C.c_void_p()
+    assert ctx.lib.vw_host_alloc(ctx.handle, 4096, C.byref(ptr)) == N.VW_OK and ptr.value
+    assert ctx.lib.vw_host_free(ctx.handle, ptr) == N.VW_OK
+    assert ctx.lib.vw_host_free(ctx.handle, None) == N.VW_OK
+    assert ctx.lib.vw_host_alloc(ctx.handle, 16, None) == N.VW_E_NULL

@@ -107,6 +107,8 @@ SIGNATURES = {
     "vw_swt_sparsify_batch_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "vw_swt_densify_batch": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp]),
     "vw_swt_densify_batch_dev": (C.c_int32, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
+    "vw_host_alloc": (C.c_int32, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "vw_host_free": (C.c_int32, [_vp, _vp]),
     "vw_transpose": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
     "vw_transpose_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, _vp, _vp]),
     "vw_swt_universal_threshold_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, C.c_double, _vp]),
@@ -194,6 +196,25 @@ class Context:
 
     def performance_info(self) -> str:
         return self.lib.vw_performance_info(self.handle).decode()
+
+    def host_array(self, shape, dtype="float64"):
+        """A NumPy array over page-locked host memory (vw_host_alloc): the host-pointer entry points copy such
+        buffers by DMA at the PCIe rate.  The memory is released when the array is garbage-collected."""
+        import numpy as np
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape))
+        if count == 0:
+            return np.empty(shape, dtype=dt)
+        ptr = C.c_void_p()
+        st = self.lib.vw_host_alloc(self.handle, count * dt.itemsize, C.byref(ptr))
+        if st != VW_OK:
+            raise MemoryError(self.last_error())
+        buf = (C.c_char * (count * dt.itemsize)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+        lib, handle, address = self.lib, self.handle, ptr.value
+        import weakref
+        weakref.finalize(buf, lambda: lib.vw_host_free(handle, C.c_void_p(address)))
+        return arr
 
     def synchronize(self):
         return self.lib.vw_synchronize(self.handle)

@@ -135,6 +135,28 @@ extern "C" int32_t vw_synchronize(vw_ctx* ctx) {
 }
 
 // MultiLevelMODWTTransform.calculateMaxLevels (modwt/MultiLevelMODWTTransform.java:477-523)
+extern "C" int32_t vw_host_alloc(vw_ctx* ctx, size_t bytes, void** out) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (out == nullptr) return set_err(ctx, VW_E_NULL, "result pointer cannot be null");
+    *out = nullptr;
+    if (bytes == 0) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return set_err(ctx, VW_E_NOMEM, "cannot page-lock %zu bytes of host memory", bytes);
+    }
+    return VW_OK;
+}
+
+extern "C" int32_t vw_host_free(vw_ctx* ctx, void* ptr) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (ptr == nullptr) return VW_OK;
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    VW_HIP(ctx, hipHostFree(ptr));
+    return VW_OK;
+}
+
 extern "C" int32_t vw_max_levels(int64_t n, int32_t filter_len) {
     if (n <= filter_len) return 0;
     int max_level = 1;
