@@ -192,3 +192,14 @@ def test_c_abi_argument_checks(ctx):
     assert call(2) == N.VW_OK
     assert ctx.lib.vw_stream_state_samples_processed(state) == 32
     assert ctx.lib.vw_stream_state_destroy(ctx.handle, state) == N.VW_OK
+
+
+@pytest.mark.parametrize("hook", ["VW_NO_REG_SELECT", "VW_NO_STD_CHAINS"])
+def test_long_row_kernels_on_short_rows(ctx, monkeypatch, hook):
+    # the 256-lane LDS kernels normally serve rings and blocks beyond 2048 samples; the hooks route short rows
+    # through them too, so their whole logic is exercised on the shapes the oracle checks quickly
+    monkeypatch.setenv(hook, "1")
+    for est in (o.NOISE_MAD, o.NOISE_STD):
+        for mult in (1.0, 1.5):
+            _run_and_compare(ctx, "db4", 3, 300, 128, 3, P, o.UNIVERSAL, True, mult, est, seed=est + 10)
+            _run_and_compare(ctx, "db4", 3, 100, 1000, 3, P, o.MINIMAX, False, mult, est, seed=est + 20)

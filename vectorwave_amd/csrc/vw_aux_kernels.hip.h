@@ -254,9 +254,7 @@ __device__ double median_select(const Src& src, int64_t n, unsigned* hist /*256*
 }
 
 
-// The same selection by ONE wavefront (workgroups of 64 lanes): no cross-wave traffic, the bin that holds
-// rank k is found with a ballot and broadcast with a shuffle.  Short rows finish several times sooner this
-// way because a pass costs no workgroup barriers and eight times as many rows are resident per CU.
+// wavefront-wide reductions (every lane gets the result)
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -272,105 +270,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-template <typename Src>
-__device__ unsigned long long wave_radix_select(const Src& src, int64_t n, int64_t k, unsigned* hist /*256, 16-byte aligned*/) {
-    const int lane = threadIdx.x;
-    unsigned long long prefix = 0;
-    int64_t kk = k;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
-        for (int64_t base = 0; base < n; base += 64) {
-            const int64_t i = base + lane;
-            unsigned long long key = 0;
-            bool match = false;
-            if (i < n) {
-                key = src.get(i);
-                match = (key & himask) == prefix;
-            }
-            const unsigned bin = static_cast<unsigned>(key >> shift) & 0xffu;
-            // Keys of one row mostly share their leading bytes, and atomics of a wavefront on one address are
-            // served one by one: the lanes that agree with the first matching lane are counted with a ballot
-            // and added once, the rest go through the atomic unit.
-            const unsigned long long active = __ballot(match);
-            if (active != 0) {
-                const int leader = __ffsll(static_cast<long long>(active)) - 1;
-                const unsigned b0 = __shfl(bin, leader, 64);
-                const unsigned long long same = __ballot(match && bin == b0);
-                if (lane == leader)
-                    atomicAdd(&hist[b0], static_cast<unsigned>(__popcll(same)));
-                else if (match && bin != b0)
-                    atomicAdd(&hist[bin], 1u);
-            }
-        }
-        __syncthreads();
-        // lane L owns bins 4L..4L+3
-        const uint4 c = reinterpret_cast<const uint4*>(hist)[lane];
-        const unsigned tot = c.x + c.y + c.z + c.w;
-        const unsigned inc = wave_inclusive_scan(tot);
-        const unsigned exc = inc - tot;
-        const bool mine = tot != 0 && static_cast<int64_t>(exc) <= kk && kk < static_cast<int64_t>(inc);
-        unsigned bin = 0, below = exc, held = c.x;
-        if (mine) {
-            if (kk >= static_cast<int64_t>(below + c.x)) {
-                below += c.x;
-                bin = 1;
-                held = c.y;
-                if (kk >= static_cast<int64_t>(below + c.y)) {
-                    below += c.y;
-                    bin = 2;
-                    held = c.z;
-                    if (kk >= static_cast<int64_t>(below + c.z)) {
-                        below += c.z;
-                        bin = 3;
-                        held = c.w;
-                    }
-                }
-            }
-        }
-        const int owner = __ffsll(static_cast<long long>(__ballot(mine))) - 1;  // exactly one lane holds rank kk
-        const unsigned sel = __shfl(static_cast<unsigned>(lane) * 4u + bin, owner, 64);
-        const unsigned nb = __shfl(below, owner, 64);
-        const unsigned in_bin = __shfl(held, owner, 64);
-        prefix |= static_cast<unsigned long long>(sel) << shift;
-        kk -= static_cast<int64_t>(nb);
-        __syncthreads();
-        if (in_bin == 1 && shift > 0) {
-            // one key left under this prefix: it is the answer, fetch it instead of descending further
-            const unsigned long long mask = ~0ull << shift;
-            unsigned long long found = ~0ull;
-            for (int64_t i = lane; i < n; i += 64) {
-                const unsigned long long key = src.get(i);
-                if ((key & mask) == prefix) found = key;
-            }
-            return wave_min_u64(found);
-        }
-    }
-    return prefix;
-}
-
-template <typename Src>
-__device__ double wave_median_select(const Src& src, int64_t n, unsigned* hist) {
-    const int lane = threadIdx.x;
-    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
-    const unsigned long long v1 = wave_radix_select(src, n, k1, hist);
-    if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
-    unsigned long long le = 0, above = ~0ull;
-    for (int64_t i = lane; i < n; i += 64) {
-        const unsigned long long key = src.get(i);
-        if (key <= v1)
-            ++le;
-        else if (key < above)
-            above = key;
-    }
-    le = wave_sum_u64(le);
-    above = wave_min_u64(above);
-    const unsigned long long v2 = (static_cast<int64_t>(le) >= k1 + 2) ? v1 : above;
-    return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
-}
-
-// LDS scratch of the selection helpers for a workgroup of NT lanes (64: one wavefront; kThreads: four)
+// LDS scratch of the 256-lane selection helpers
 template <int NT>
 struct SelLds {
     __align__(16) unsigned hist[256];
@@ -378,36 +278,26 @@ struct SelLds {
     unsigned long long bcast[2];
     unsigned long long red[kThreads];
 };
-template <>
-struct SelLds<64> {
-    __align__(16) unsigned hist[256];
-};
 
 template <int NT, typename Src>
 __device__ __forceinline__ double median_nt(const Src& src, int64_t n, SelLds<NT>& l) {
-    if constexpr (NT == 64)
-        return wave_median_select(src, n, l.hist);
-    else
-        return median_select(src, n, l.hist, l.wsum, l.bcast, l.red);
+    static_assert(NT == kThreads, "the LDS-histogram selection runs with 256 lanes");
+    return median_select(src, n, l.hist, l.wsum, l.bcast, l.red);
 }
 
 // sum of one value per lane over the workgroup; every lane gets it
 template <int NT>
 __device__ __forceinline__ unsigned long long sum_nt(unsigned long long v, SelLds<NT>& l) {
-    if constexpr (NT == 64) {
-        return wave_sum_u64(v);
-    } else {
-        const int tid = threadIdx.x;
-        l.red[tid] = v;
+    const int tid = threadIdx.x;
+    l.red[tid] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) l.red[tid] += l.red[tid + s];
         __syncthreads();
-        for (int s = kThreads / 2; s > 0; s >>= 1) {
-            if (tid < s) l.red[tid] += l.red[tid + s];
-            __syncthreads();
-        }
-        const unsigned long long r = l.red[0];
-        __syncthreads();
-        return r;
     }
+    const unsigned long long r = l.red[0];
+    __syncthreads();
+    return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -756,8 +646,8 @@ __device__ __forceinline__ unsigned stratified_pick(unsigned k, unsigned n, unsi
     return start + (i * step) % len;
 }
 
-// NT = 64: one wavefront per stream, for rings and blocks short enough that a lane's share of a selection
-// pass is a few dozen keys; NT = kThreads otherwise.  n and w are below 2^31 (checked by the host).
+// 256 lanes per stream: rings and blocks too long for the register-resident kernels below, and the ring update
+// of the STD estimator.  n and w are below 2^31 (checked by the host).
 template <int NT>
 __global__ void __launch_bounds__(NT) k_stream_noise(const StreamNoiseArgs a) {
 #pragma clang fp contract(off)

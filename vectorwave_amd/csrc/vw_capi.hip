@@ -1057,9 +1057,6 @@ extern "C" int32_t vw_threshold(vw_ctx* ctx, const double* in, int64_t count, do
 
 static double host_sqrt_2_ln_n(int64_t n) { return sqrt(2 * log(static_cast<double>(n))); }
 
-// rows of up to kWaveSelectMax samples go one wavefront per row, longer rows one 256-lane workgroup per row
-static constexpr int64_t kWaveSelectMax = 2048;
-
 // keys per lane of the register-resident selection kernels for a row of n samples, 0 when it is too long
 static int reg_kpl(int64_t n) {
     if (getenv("VW_NO_REG_SELECT") != nullptr) return 0;
@@ -1079,10 +1076,7 @@ static void launch_universal_threshold(const MedianArgs& a, int64_t b, int64_t n
         case 32: hipLaunchKernelGGL(k_universal_threshold_reg<32>, grid, dim3(64), 0, s, a); return;
         default: break;
     }
-    if (n <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
-        hipLaunchKernelGGL(k_universal_threshold<64>, grid, dim3(64), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_universal_threshold<kThreads>, grid, dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL(k_universal_threshold<kThreads>, grid, dim3(kThreads), lds, s, a);
 }
 
 static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels,
@@ -1635,22 +1629,14 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
         a.lds_cap = 6144;
         if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
         // one launch updates the ring, estimates the level and (with a multiplier) derives the threshold; the STD
-        // estimator runs between two such launches in a kernel of its own that walks 64 rings per wavefront
+        // estimator runs between two such launches in a kernel of its own that walks 16 rings per wavefront
         auto launch = [&](int do_update, int do_level, int want_thr) {
             a.do_update = do_update;
             a.do_level = do_level;
             a.want_thr = want_thr;
-            int64_t staged = 0, longest = 0;
-            if (do_update && n < state->window) longest = n;
-            if (do_update && n >= state->window) longest = state->window;
-            if (do_level) {
-                longest = state->window;
-                if (state->window <= a.lds_cap) staged = state->window;
-            }
-            if (want_thr) {
-                if (n > longest) longest = n;
-                if (n <= a.lds_cap && n > staged) staged = n;
-            }
+            int64_t staged = 0;  // doubles of LDS the 256-lane kernel stages a ring or a block in
+            if (do_level && state->window <= a.lds_cap) staged = state->window;
+            if (want_thr && n <= a.lds_cap && n > staged) staged = n;
             const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
             const dim3 grid(static_cast<unsigned>(b));
             if (do_level == do_update && !(do_level && noise_estimation == VW_NOISE_STD)) {  // MAD, or the threshold alone
@@ -1671,10 +1657,7 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
                     return;
                 }
             }
-            if (longest <= kWaveSelectMax && getenv("VW_NO_WAVE_SELECT") == nullptr)
-                hipLaunchKernelGGL(k_stream_noise<64>, dim3(static_cast<unsigned>(b)), dim3(64), lds, s, a);
-            else
-                hipLaunchKernelGGL(k_stream_noise<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
+            hipLaunchKernelGGL(k_stream_noise<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
         };
         if (noise_estimation == VW_NOISE_STD && getenv("VW_NO_STD_CHAINS") == nullptr) {
             launch(1, 0, 0);
