@@ -76,3 +76,44 @@ def test_random_denoise(ctx, wn, n, j, b, mode, seed):
                                                                          return_thresholds=True)
     assert_bits_equal(gthr, wthr, "WaveletDenoiser thresholds %s N=%d J=%d method=%d" % (wn, n, j, method))
     assert_bits_equal(gotd, wantd, "WaveletDenoiser %s N=%d J=%d method=%d" % (wn, n, j, method))
+
+
+def _stream_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        wn = ["haar", "db2", "db4", "sym8", "coif1"][rng.integers(5)]
+        n = int([1, 2, 3, 8, 31, 32, 33, 64, 65, 100, 255, 256, 480, 1000, 2049][rng.integers(15)])
+        window = int([1, 2, 7, 10, 11, 63, 64, 100, 256, 1000, 1024, 2048, 2500][rng.integers(13)])
+        est = int(rng.integers(3))
+        mult = [1.0, 1.0, 0.5, 1.5, 3.0][rng.integers(5)]
+        method = int([0, 1, 2, 3, 0, 1, 2, 4][rng.integers(8)])
+        if mult == 1.0 and method == 4:
+            method = 0
+        if mult != 1.0 and method == 3:
+            method = 2
+        out.append((wn, n, window, est, mult, method, int(rng.integers(3)), bool(rng.integers(2)), int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("wn,n,window,est,mult,method,mode,soft,seed", _stream_cases(20250303, 80))
+def test_random_streaming_denoiser(ctx, wn, n, window, est, mult, method, mode, soft, seed):
+    from vectorwave_amd import (BoundaryMode, MODWTStreamingDenoiser, NoiseEstimation, ThresholdMethod, ThresholdType)
+    w = get_wavelet(wn)
+    rng = np.random.default_rng(seed)
+    streams = 3
+    state = o.StreamingDenoiserState(streams, window)
+    den = (MODWTStreamingDenoiser.Builder().wavelet(w).boundaryMode(BoundaryMode(mode)).noiseWindowSize(window)
+           .thresholdMethod(ThresholdMethod(method)).thresholdType(ThresholdType.SOFT if soft else ThresholdType.HARD)
+           .thresholdMultiplier(mult).noiseEstimation(NoiseEstimation(est)).streams(streams).context(ctx).build())
+    with den:
+        for k in range(4):
+            blk = np.ascontiguousarray(np.sin(np.arange(n) / 3.0 + k)[None] + 0.2 * rng.standard_normal((streams, n)))
+            st, want, _ = o.streaming_denoise_batch(state, blk, w, method, soft, mult, est, mode)
+            assert st == 0
+            tag = "%s n=%d ring=%d est=%d mult=%g method=%d mode=%d block %d" % (wn, n, window, est, mult, method, mode, k)
+            assert_bits_equal(den.denoise(blk), want, tag)
+            win, idx = den.getNoiseWindow()
+            assert idx == state.index
+            assert_bits_equal(win, state.window, "ring " + tag)
+            assert_bits_equal(den.getEstimatedNoiseLevel(), state.level, "level " + tag)
