@@ -626,4 +626,93 @@ struct BatchSIMDMODWT {
     }
 };
 
+// swt/SWTResult.java: dense container (level index 0-based as in the reference) and its sparse form, whose
+// compaction and expansion run on the GPU
+class SparseSWTResult;
+class SWTResult {
+  public:
+    SWTResult(std::vector<double> approximation, std::vector<std::vector<double>> details, int levels, std::shared_ptr<Context> ctx = defaultContext())
+        : a_(std::move(approximation)), d_(std::move(details)), levels_(levels), ctx_(ctx) {
+        // :43-60
+        if (static_cast<int>(d_.size()) != levels) throw std::invalid_argument("Details array length must match levels");
+        for (const auto& d : d_)
+            if (d.size() != a_.size()) throw std::invalid_argument("All detail levels must have same length as approximation");
+    }
+    std::vector<double> getApproximation() const { return a_; }
+    std::vector<double> getDetail(int level) const { checkLevel(level); return d_[static_cast<size_t>(level)]; }
+    int getLevels() const { return levels_; }
+    int getSignalLength() const { return static_cast<int>(a_.size()); }
+    double getDetailEnergy(int level) const { checkLevel(level); return energy(d_[static_cast<size_t>(level)]); }  // :124-147
+    double getApproximationEnergy() const { return energy(a_); }
+    double getTotalEnergy() const {  // :168-181
+        double e = getApproximationEnergy();
+        for (int l = 0; l < levels_; ++l) e += getDetailEnergy(l);
+        return e;
+    }
+    inline SparseSWTResult toSparse(double threshold) const;  // :190-192
+
+  private:
+    friend class SparseSWTResult;
+    void checkLevel(int level) const {
+        if (level < 0 || level >= levels_) throw std::invalid_argument("Level must be between 0 and " + std::to_string(levels_ - 1));
+    }
+    static double energy(const std::vector<double>& v) {
+        double e = 0.0;
+        for (double c : v) e += c * c;
+        return e;
+    }
+    std::vector<double> a_;
+    std::vector<std::vector<double>> d_;
+    int levels_;
+    std::shared_ptr<Context> ctx_;
+};
+
+// SWTResult.SparseSWTResult (:198-257)
+class SparseSWTResult {
+  public:
+    SparseSWTResult(const SWTResult& full, double threshold) : a_(full.a_), levels_(full.levels_), n_(static_cast<int64_t>(full.a_.size())), threshold_(threshold), ctx_(full.ctx_) {
+        std::vector<double> block(static_cast<size_t>(levels_ + 1) * n_);
+        for (int l = 0; l < levels_; ++l) std::copy(full.d_[static_cast<size_t>(l)].begin(), full.d_[static_cast<size_t>(l)].end(), block.begin() + static_cast<int64_t>(l) * n_);
+        std::vector<int64_t> counts(static_cast<size_t>(levels_), 0);
+        if (n_ > 0) ctx_->check(vw_swt_sparsify_batch(ctx_->get(), block.data(), 1, n_, levels_, threshold_, counts.data(), nullptr, nullptr, nullptr));
+        offsets_.assign(static_cast<size_t>(levels_) + 1, 0);
+        for (int l = 0; l < levels_; ++l) offsets_[static_cast<size_t>(l) + 1] = offsets_[static_cast<size_t>(l)] + counts[static_cast<size_t>(l)];
+        indices_.resize(static_cast<size_t>(offsets_.back()));
+        values_.resize(static_cast<size_t>(offsets_.back()));
+        if (offsets_.back() > 0)
+            ctx_->check(vw_swt_sparsify_batch(ctx_->get(), block.data(), 1, n_, levels_, threshold_, nullptr, offsets_.data(), indices_.data(), values_.data()));
+    }
+    // :225-231
+    SWTResult toFull() const {
+        std::vector<double> block(static_cast<size_t>(levels_ + 1) * n_, 0.0);
+        if (n_ > 0) ctx_->check(vw_swt_densify_batch(ctx_->get(), offsets_.data(), indices_.data(), values_.data(), 1, n_, levels_, block.data()));
+        std::vector<std::vector<double>> d(static_cast<size_t>(levels_));
+        for (int l = 0; l < levels_; ++l) d[static_cast<size_t>(l)].assign(block.begin() + static_cast<int64_t>(l) * n_, block.begin() + static_cast<int64_t>(l + 1) * n_);
+        return SWTResult(a_, d, levels_, ctx_);
+    }
+    // :238-247
+    double getCompressionRatio() const {
+        const int64_t original = n_ * (levels_ + 1);
+        const int64_t compressed = n_ + 2 * offsets_.back();
+        return static_cast<double>(original) / static_cast<double>(compressed);
+    }
+    double getThreshold() const { return threshold_; }
+    int64_t getNonZeroCount(int level) const { return offsets_[static_cast<size_t>(level) + 1] - offsets_[static_cast<size_t>(level)]; }
+    const std::vector<int32_t>& indices() const { return indices_; }
+    const std::vector<double>& values() const { return values_; }
+    const std::vector<int64_t>& offsets() const { return offsets_; }
+
+  private:
+    std::vector<double> a_;
+    int levels_;
+    int64_t n_;
+    double threshold_;
+    std::shared_ptr<Context> ctx_;
+    std::vector<int64_t> offsets_;
+    std::vector<int32_t> indices_;
+    std::vector<double> values_;
+};
+
+inline SparseSWTResult SWTResult::toSparse(double threshold) const { return SparseSWTResult(*this, threshold); }
+
 }  // namespace vectorwave

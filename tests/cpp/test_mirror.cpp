@@ -20,6 +20,7 @@ int vwo_wavelet_denoise_batch(const double*, int64_t, int64_t, int, const double
 int vwo_streaming_denoise_batch(const double*, int64_t, int64_t, const double*, int, const double*, int, const double*, int, const double*, int, int, int,
                                 int, double, int, double*, int64_t, int64_t*, double*, double*, double*);
 void vwo_batch_modwt_soa(const double*, double*, double*, const double*, const double*, int, int, int64_t, int64_t);
+int64_t vwo_sparse_vector(const double*, int64_t, double, int32_t*, double*);
 }
 
 using namespace vectorwave;
@@ -212,6 +213,38 @@ int main() {
             CHECK(bits_equal(a, wa));
             CHECK(bits_equal(d, wd));
         }
+    }
+    {
+        // SWTResult: sparse form against the oracle's SparseVector, and the round trip
+        const int levels = 3;
+        const int64_t n = 1500;
+        auto a = make_signal(n, 21);
+        std::vector<std::vector<double>> d;
+        for (int l = 0; l < levels; ++l) d.push_back(make_signal(n, 30 + l));
+        SWTResult full(a, d, levels);
+        SparseSWTResult sp = full.toSparse(0.8);
+        int64_t kept = 0;
+        for (int l = 0; l < levels; ++l) {
+            std::vector<int32_t> wi(n);
+            std::vector<double> wv(n);
+            const int64_t cnt = vwo_sparse_vector(d[l].data(), n, 0.8, wi.data(), wv.data());
+            CHECK(sp.getNonZeroCount(l) == cnt);
+            bool same = true;
+            for (int64_t i = 0; i < cnt; ++i) same = same && sp.indices()[sp.offsets()[l] + i] == wi[i] && sp.values()[sp.offsets()[l] + i] == wv[i];
+            CHECK(same);
+            kept += cnt;
+        }
+        CHECK(sp.getCompressionRatio() == static_cast<double>(n * (levels + 1)) / static_cast<double>(n + 2 * kept));
+        SWTResult back = sp.toFull();
+        CHECK(bits_equal(back.getApproximation(), a));
+        for (int l = 0; l < levels; ++l) {
+            std::vector<double> want(n);
+            for (int64_t i = 0; i < n; ++i) want[i] = std::fabs(d[l][i]) > 0.8 ? d[l][i] : 0.0;
+            CHECK(bits_equal(back.getDetail(l), want));
+        }
+        bool threw = false;
+        try { SWTResult bad(a, d, levels + 1); } catch (const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
     }
     std::printf(failures == 0 ? "cpp mirror: all checks passed\n" : "cpp mirror: %d checks FAILED\n", failures);
     return failures == 0 ? 0 : 1;
