@@ -348,7 +348,9 @@ static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, 
 // Run length of the long-context kernels: long enough to amortise the warm-up tiles, short enough to
 // fill the chip.  VW_SDRY_CHUNKS overrides (test / tuning hook).
 static void sdry_runs(int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out) {
-    int64_t nseg = rows > 0 ? (2048 + rows - 1) / rows : 1;
+    // about 1024 runs in all: two 512-lane workgroups fit a CU, and longer runs amortise the warm-up tiles better
+    // than a third and fourth wave of workgroups would (sym8 J=8 on 64 x 777777: 24-48 tiles per run measured best)
+    int64_t nseg = rows > 0 ? (1024 + rows - 1) / rows : 1;
     if (nseg > tiles) nseg = tiles;
     if (nseg < 1) nseg = 1;
     int64_t nch = (tiles + nseg - 1) / nseg;
