@@ -152,3 +152,68 @@ def test_gpu_reproduces_extra_golden_vectors(ctx):
         st, r, _ = gpu_inverse(ctx, np.ascontiguousarray(z[key + "_coeffs"]), wn, mode)
         assert st == 0, ctx.last_error()
         assert_bits_equal(r, z[key + "_recon"], key + " recon")
+
+
+# ---- third fixture: streaming denoiser / streaming transforms / sparse SWT result ---------------------
+
+def _streaming():
+    z = np.load(os.path.join(GOLD, "streaming_sparse_vectors.npz"))
+    cases = []
+    for key in z["_streaming_cases"]:
+        key = str(key)
+        wn, n, ring, est, method, mult, soft, mode = key.split("_")
+        cases.append((key, wn, int(n[1:]), int(ring[1:]), int(est[1:]), int(method[1:]), float(mult[1:]), int(soft[1:]), int(mode[1:])))
+    return z, cases
+
+
+def test_oracle_reproduces_streaming_golden_vectors():
+    z, cases = _streaming()
+    assert len(cases) == 6
+    for key, wn, n, ring, est, method, mult, soft, mode in cases:
+        w = get_wavelet(wn)
+        state = o.StreamingDenoiserState(2, ring)
+        for k, blk in enumerate(z[key + "_x"]):
+            st, y, _ = o.streaming_denoise_batch(state, blk, w, method, bool(soft), mult, est, mode)
+            assert st == 0
+            assert_bits_equal(y, z[key + "_y"][k], key + " block %d" % k)
+            assert_bits_equal(state.level, z[key + "_level"][k], key + " level %d" % k)
+            assert_bits_equal(state.window, z[key + "_ring"][k], key + " ring %d" % k)
+    w = get_wavelet("db4")
+    t = o.StreamingTransformState(w, 128, 0)
+    assert_bits_equal(np.concatenate([t.process(z["xform_x"]), t.flush()]), z["xform_blocks"], "streaming transform blocks")
+    assert_bits_equal(o.stream_multilevel(z["xform_x"], w, 128, 3, 0)[1], z["xform_multilevel_blocks"], "multi-level blocks")
+    idx, val = o.sparse_vector(z["sparse_dense"], 0.6)
+    assert np.array_equal(idx, z["sparse_idx"])
+    assert_bits_equal(val, z["sparse_val"], "sparse values")
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_streaming_golden_vectors(ctx):
+    from vectorwave_amd import (BoundaryMode, MODWTStreamingDenoiser, MODWTStreamingTransform, NoiseEstimation, SWTResult,
+                                ThresholdMethod, ThresholdType)
+    z, cases = _streaming()
+    for key, wn, n, ring, est, method, mult, soft, mode in cases:
+        den = (MODWTStreamingDenoiser.Builder().wavelet(wn).boundaryMode(BoundaryMode(mode)).noiseWindowSize(ring)
+               .thresholdMethod(ThresholdMethod(method)).thresholdType(ThresholdType.SOFT if soft else ThresholdType.HARD)
+               .thresholdMultiplier(mult).noiseEstimation(NoiseEstimation(est)).streams(2).context(ctx).build())
+        with den:
+            for k, blk in enumerate(z[key + "_x"]):
+                assert_bits_equal(den.denoise(np.ascontiguousarray(blk)), z[key + "_y"][k], key + " block %d" % k)
+                assert_bits_equal(den.getEstimatedNoiseLevel(), z[key + "_level"][k], key + " level %d" % k)
+                assert_bits_equal(den.getNoiseWindow()[0], z[key + "_ring"][k], key + " ring %d" % k)
+    got = []
+    with MODWTStreamingTransform.create("db4", BoundaryMode.PERIODIC, 128, ctx=ctx) as t:
+        t.subscribe(lambda r: got.append([r.detailCoeffs(), r.approximationCoeffs()]))
+        t.process(z["xform_x"][:300])
+        t.process(z["xform_x"][300:])
+    assert_bits_equal(np.array(got), z["xform_blocks"], "streaming transform blocks")
+    got = []
+    with MODWTStreamingTransform.createMultiLevel("db4", BoundaryMode.PERIODIC, 128, 3, streams=2, ctx=ctx) as t:
+        t.subscribe(got.append)
+        t.process(np.stack([z["xform_x"], z["xform_x"]]))
+    assert_bits_equal(np.array(got)[:, 1], z["xform_multilevel_blocks"], "multi-level blocks")
+    d = z["sparse_dense"]
+    sp = SWTResult(np.zeros(d.size), [d], 1, ctx).toSparse(0.6)
+    idx, val = sp.getSparseDetail(0)
+    assert np.array_equal(idx, z["sparse_idx"])
+    assert_bits_equal(val, z["sparse_val"], "sparse values")

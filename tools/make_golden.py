@@ -101,6 +101,7 @@ def main():
     sz = os.path.getsize(os.path.join(OUT, "oracle_vectors.npz"))
     print("wrote %d cases, %.1f KiB" % (len(names), sz / 1024))
     make_extra()
+    make_streaming()
 
 
 # second fixture: the WaveletDenoiser path and level groups with a long context (more than one
@@ -137,6 +138,49 @@ def make_extra():
     path = os.path.join(OUT, "denoiser_longcontext_vectors.npz")
     np.savez_compressed(path, **arrays)
     print("wrote %d + %d extra cases, %.1f KiB" % (len(dn), len(lc), os.path.getsize(path) / 1024))
+
+
+# third fixture: the streaming callers (block sequences with their state) and the sparse SWT result
+STREAMING_CASES = [  # wavelet, block length, ring length, estimation, method, multiplier, soft, boundary
+    ("db4", 96, 256, 0, 0, 1.0, 1, 0), ("db4", 96, 64, 0, 0, 1.5, 1, 0), ("haar", 50, 128, 1, 2, 0.7, 0, 1),
+    ("sym8", 120, 100, 1, 1, 1.0, 1, 2), ("db4", 80, 32, 2, 4, 2.0, 1, 0), ("db4", 300, 10, 0, 1, 1.2, 0, 0),
+]
+
+
+def make_streaming():
+    arrays, names = {}, []
+    for wn, n, ring, est, method, mult, soft, mode in STREAMING_CASES:
+        w = get_wavelet(wn)
+        key = "%s_n%d_w%d_e%d_M%d_x%g_S%d_m%d" % (wn, n, ring, est, method, mult, soft, mode)
+        state = o.StreamingDenoiserState(2, ring)
+        rng = np.random.default_rng(4000 + n + ring)
+        blocks = np.sin(np.arange(4 * n).reshape(4, 1, n) / 7.0) + 0.2 * rng.standard_normal((4, 2, n))
+        outs, levels, rings = [], [], []
+        for blk in blocks:
+            st, y, _ = o.streaming_denoise_batch(state, blk, w, method, bool(soft), mult, est, mode)
+            assert st == 0, key
+            outs.append(y)
+            levels.append(state.level.copy())
+            rings.append(state.window.copy())
+        arrays[key + "_x"], arrays[key + "_y"] = blocks, np.array(outs)
+        arrays[key + "_level"], arrays[key + "_ring"] = np.array(levels), np.array(rings)
+        names.append(key)
+    # block transforms over one stream fed in uneven pieces
+    x = signals(1, 1000, seed=4100)[0]
+    w = get_wavelet("db4")
+    t = o.StreamingTransformState(w, 128, 0)
+    arrays["xform_x"] = x
+    arrays["xform_blocks"] = np.concatenate([t.process(x), t.flush()])
+    st, ml = o.stream_multilevel(x, w, 128, 3, 0)
+    arrays["xform_multilevel_blocks"] = ml
+    # sparse detail band
+    d = signals(1, 500, seed=4200)[0] - 0.3
+    idx, val = o.sparse_vector(d, 0.6)
+    arrays["sparse_dense"], arrays["sparse_idx"], arrays["sparse_val"] = d, idx, val
+    arrays["_streaming_cases"] = np.array(names)
+    path = os.path.join(OUT, "streaming_sparse_vectors.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %d streaming cases, %.1f KiB" % (len(names), os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":
