@@ -98,3 +98,26 @@ def test_swt_result_mirror(ctx):
         res.getDetail(levels)
     with pytest.raises(TypeError):
         SWTResult(None, d, levels)
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_argument_checks(ctx):
+    from vectorwave_amd import _native as N
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    coeffs = np.ones((1, 3, 8))
+    idx = np.zeros(16, dtype=np.int32)
+    val = np.zeros(16)
+    bad = np.array([0, 9, 3], dtype=np.int64)        # decreasing
+    assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), 1, 8, 2, 0.5, None, vp(bad), vp(idx), vp(val)) == N.VW_E_LENGTH_MISMATCH
+    neg = np.array([-1, 0, 3], dtype=np.int64)
+    assert ctx.lib.vw_swt_densify_batch(ctx.handle, vp(neg), vp(idx), vp(val), 1, 8, 2, vp(coeffs)) == N.VW_E_NOT_POSITIVE
+    # an index outside the band is dropped, not written
+    offs = np.array([0, 2, 2], dtype=np.int64)
+    idx[:2] = [3, 100]
+    val[:2] = [5.0, 6.0]
+    out = np.full((1, 3, 8), 7.0)
+    assert ctx.lib.vw_swt_densify_batch(ctx.handle, vp(offs), vp(idx), vp(val), 1, 8, 2, vp(out)) == N.VW_OK
+    want = np.zeros((2, 8))
+    want[0, 3] = 5.0
+    assert np.array_equal(out[0, :2], want) and np.all(out[0, 2] == 7.0)
+    assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), 1, 8, 0, 0.5, vp(offs), None, None, None) == N.VW_E_LEVEL

@@ -1233,6 +1233,7 @@ struct DensifyArgs {
     const double* values;
     double* out;             // band b at out + (b / levels)*row_stride + (b % levels)*band_stride, zeroed beforehand
     int64_t row_stride, band_stride;
+    int64_t n;
     int32_t levels;
 };
 
@@ -1242,7 +1243,10 @@ __global__ void __launch_bounds__(kThreads) k_densify(const DensifyArgs a) {
     const int level = static_cast<int>(band - row * a.levels);
     double* out = a.out + row * a.row_stride + static_cast<int64_t>(level) * a.band_stride;
     const int64_t e0 = a.offsets[band], e1 = a.offsets[band + 1];
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += kThreads) out[a.indices[e]] = a.values[e];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += kThreads) {
+        const int64_t i = a.indices[e];
+        if (i >= 0 && i < a.n) out[i] = a.values[e];  // an index outside the band is the caller's error, not a reason to write there
+    }
 }
 
 }  // namespace vw

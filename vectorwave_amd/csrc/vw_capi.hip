@@ -1743,6 +1743,17 @@ static int sparse_checks(vw_ctx* ctx, const void* p0, int64_t b, int64_t n, int 
     return VW_OK;
 }
 
+// offsets must be a prefix sum: starting at 0 or above, never decreasing, no band with more than n entries (the
+// kernels write where it says, so a wrong array would send them outside the buffers sized from its last entry)
+static int check_offsets(vw_ctx* ctx, const int64_t* offsets, int64_t bands, int64_t n) {
+    if (offsets[0] < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative offset");
+    for (int64_t k = 0; k < bands; ++k)
+        if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] > n)
+            return set_err(ctx, VW_E_LENGTH_MISMATCH, "offsets[%lld..%lld] is not the prefix sum of band counts", static_cast<long long>(k),
+                           static_cast<long long>(k + 1));
+    return VW_OK;
+}
+
 extern "C" int32_t vw_swt_sparsify_batch_dev(vw_ctx* ctx, const double* coeffs_dev, int64_t b, int64_t n, int32_t levels,
                                              double threshold, int64_t* counts_dev, const int64_t* offsets_dev,
                                              int32_t* indices_dev, double* values_dev, void* stream) {
@@ -1798,7 +1809,8 @@ extern "C" int32_t vw_swt_sparsify_batch(vw_ctx* ctx, const double* coeffs, int6
         return VW_OK;
     }
     const int64_t total = offsets[bands];  // the caller's prefix sum ends with the number of entries
-    if (total < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative entry count");
+    rc = check_offsets(ctx, offsets, bands, n);
+    if (rc != VW_OK) return rc;
     const size_t obytes = round256(static_cast<size_t>(bands) * 8);
     const size_t ibytes = round256(static_cast<size_t>(total) * 4);
     rc = ensure(ctx, ctx->stage_out, obytes + ibytes + static_cast<size_t>(total) * 8 + 256);
@@ -1840,6 +1852,7 @@ extern "C" int32_t vw_swt_densify_batch_dev(vw_ctx* ctx, const int64_t* offsets_
     a.out = coeffs_out_dev;
     a.row_stride = rowc;
     a.band_stride = n;
+    a.n = n;
     a.levels = levels;
     hipLaunchKernelGGL(k_densify, dim3(static_cast<unsigned>(b * levels)), dim3(kThreads), 0, s, a);
     VW_HIP(ctx, hipGetLastError());
@@ -1856,8 +1869,9 @@ extern "C" int32_t vw_swt_densify_batch(vw_ctx* ctx, const int64_t* offsets, con
     VW_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t bands = b * levels;
     const int64_t total = offsets[bands];
-    if (total < 0 || (total > 0 && (indices == nullptr || values == nullptr)))
-        return set_err(ctx, VW_E_NULL, "indices and values cannot be null");
+    rc = check_offsets(ctx, offsets, bands, n);
+    if (rc != VW_OK) return rc;
+    if (total > 0 && (indices == nullptr || values == nullptr)) return set_err(ctx, VW_E_NULL, "indices and values cannot be null");
     const size_t cbytes = static_cast<size_t>(b) * (levels + 1) * n * 8;
     const size_t obytes = round256(static_cast<size_t>(bands + 1) * 8);
     const size_t ibytes = round256(static_cast<size_t>(total) * 4);
