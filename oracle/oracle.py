@@ -170,6 +170,24 @@ def batch_modwt_soa(soa, wavelet, batch, n):
     return a, d
 
 
+def soa_multilevel_roundtrip(soa, wavelet, batch, n, levels):
+    """Multi-level forward + inverse in the reference's SIMD batch layout (soa[t*B + b], PERIODIC): the scheme
+    of BatchSIMDMODWT's general path applied per level.  Returns (coeffs [(J+1)][N*B] planes d_1..d_J, a_J;
+    reconstruction [N*B])."""
+    s = _f64(soa)
+    h, g = _f64(wavelet.dec_lo), _f64(wavelet.dec_hi)
+    hr, gr = _f64(wavelet.rec_lo), _f64(wavelet.rec_hi)
+    assert gr.size >= hr.size
+    coeffs = np.empty((levels + 1, n * batch))
+    scratch = np.empty(n * batch)
+    out = np.empty(n * batch)
+    lib().vwo_soa_multilevel_decompose(_p(s), C.c_int64(batch), C.c_int64(n), C.c_int(levels), _p(h), C.c_int(h.size),
+                                       _p(g), C.c_int(g.size), _p(coeffs), _p(scratch))
+    lib().vwo_soa_multilevel_reconstruct(_p(coeffs), C.c_int64(batch), C.c_int64(n), C.c_int(levels), _p(hr),
+                                         C.c_int(hr.size), _p(gr), _p(out), _p(scratch))
+    return coeffs, out
+
+
 def parallel_max_levels(n, filter_len):
     return int(lib().vwo_parallel_max_levels(C.c_int64(n), C.c_int(filter_len)))
 

@@ -1004,6 +1004,78 @@ void vwo_batch_modwt_soa(const double *soa, double *soa_approx, double *soa_deta
     }
 }
 
+/* The batch-vectorised scheme of modwt/BatchSIMDMODWT.java:216-274 (general path: running sums from
+ * zero, source index (t - l + N) % N, vector lanes along the batch of a structure-of-arrays block
+ * soa[t * batch + b]) applied level by level with the level's dilation 2^(j-1), i.e. the cascade of
+ * modwt/MultiLevelMODWTTransform.java:251-265 carried out in the reference's SIMD batch layout, followed by
+ * the inverse cascade of modwt/MultiLevelMODWTTransform.java:638-648 (pair sum lo*a + hi*d, taps ascending)
+ * in the same layout.  PERIODIC only, like the reference's batch class.  The lanes perform the same scalar
+ * operations in the same order as the per-signal path, so the results equal vwo_multilevel_decompose /
+ * vwo_multilevel_reconstruct bit for bit; only the loop nest (t outer, taps, batch inner and vectorised by
+ * the compiler; OpenMP over t) differs.  Timed by the benchmark as the second CPU baseline.
+ * coeffs: (levels + 1) planes of n * batch doubles, plane j-1 = d_j, plane `levels` = a_J (running
+ * approximation ping-pongs between that plane and `scratch`, n * batch doubles). */
+void vwo_soa_multilevel_decompose(const double *soa, int64_t batch, int64_t n, int levels, const double *h,
+                                  int lh, const double *g, int lg, double *coeffs, double *scratch) {
+    double *lo = scaled_copy(h, lh), *hi = scaled_copy(g, lg);
+    const int64_t plane = n * batch;
+    const double *cur = soa;
+    for (int j = 1; j <= levels; j++) {
+        const int64_t s = (int64_t)1 << (j - 1);
+        /* the last level must land in plane `levels` */
+        double *va = ((levels - j) % 2 == 0) ? coeffs + (int64_t)levels * plane : scratch;
+        double *wd = coeffs + (int64_t)(j - 1) * plane;
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < n; t++) {
+            double *oa = va + t * batch, *od = wd + t * batch;
+            for (int64_t b = 0; b < batch; b++) oa[b] = 0.0, od[b] = 0.0;
+            const int lmax = lh > lg ? lh : lg;
+            for (int l = 0; l < lmax; l++) {
+                int64_t src = (t - (int64_t)l * s) % n;
+                if (src < 0) src += n;
+                const double *v = cur + src * batch;
+                if (l < lh) {
+                    const double f = lo[l];
+                    for (int64_t b = 0; b < batch; b++) oa[b] = oa[b] + v[b] * f;
+                }
+                if (l < lg) {
+                    const double f = hi[l];
+                    for (int64_t b = 0; b < batch; b++) od[b] = od[b] + v[b] * f;
+                }
+            }
+        }
+        cur = va;
+    }
+    free(lo);
+    free(hi);
+}
+
+void vwo_soa_multilevel_reconstruct(const double *coeffs, int64_t batch, int64_t n, int levels, const double *hr,
+                                    int lhr, const double *gr, double *soa_out, double *scratch) {
+    double *lo = scaled_copy(hr, lhr), *hi = scaled_copy(gr, lhr);
+    const int64_t plane = n * batch;
+    const double *cur = coeffs + (int64_t)levels * plane;
+    for (int j = levels; j >= 1; j--) {
+        const int64_t s = (int64_t)1 << (j - 1);
+        double *out = ((j - 1) % 2 == 0) ? soa_out : scratch;
+        const double *wd = coeffs + (int64_t)(j - 1) * plane;
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < n; t++) {
+            double *o = out + t * batch;
+            for (int64_t b = 0; b < batch; b++) o[b] = 0.0;
+            for (int l = 0; l < lhr; l++) {
+                const int64_t src = (t + (int64_t)l * s) % n;
+                const double *a = cur + src * batch, *d = wd + src * batch;
+                const double fl = lo[l], fh = hi[l];
+                for (int64_t b = 0; b < batch; b++) o[b] = o[b] + (fl * a[b] + fh * d[b]);
+            }
+        }
+        cur = out;
+    }
+    free(lo);
+    free(hi);
+}
+
 /* modwt/ParallelMultiLevelMODWT.java:218-248 (calculateMaxLevels; note the extra
  * signalLength <= filterLength rule) */
 int vwo_parallel_max_levels(int64_t n, int filter_len) {
