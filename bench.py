@@ -471,7 +471,7 @@ def cpu_baseline(o, w, J, n, args):
             return time.perf_counter() - t0
 
         tp = run_soa(1)
-        reps = int(max(1, min(64, 8.0 / max(tp, 1e-6))))  # aim at ~8 s
+        reps = int(max(1, min(4096, 8.0 / max(tp, 1e-6))))  # aim at ~8 s
         el2 = run_soa(reps)
         soa = {
             "value": round(reps * batch * n / el2 / 1e9, 5), "unit": "Gsamples/s", "cores": cores, "kind": "port",

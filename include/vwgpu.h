@@ -119,6 +119,17 @@ int32_t vw_synchronize(vw_ctx *ctx);
 /* Number of HIP devices visible to the process (0 if none / no runtime). */
 int32_t vw_device_count(void);
 
+/* Choose among equivalent launch plans of this context (no counterpart in the reference; for tests and
+ * tuning).  Every setting yields the same results bit for bit -- the options only select tile shapes, run
+ * lengths and kernel families that the planner would otherwise pick by size, so that small test inputs can
+ * reach the plans large inputs take.  The library never reads environment variables.  Names: "fwd_tile" /
+ * "inv_tile" (value = chunks per tile * 100 + halo chunks, e.g. 401; 0 = planner's choice), "fwd_chunks"
+ * (tiles per run of the streaming forward), "stream_wgs" (workgroups wanted per streaming launch),
+ * "sdry_chunks" (run length of the long-context kernels), "no_sdry", "no_unroll", "no_reg_select",
+ * "no_std_chains", "no_row_denoise" (0/1), "nt_stores" (-1 by launch size, 0, 1), "reset" (all defaults).
+ * Unknown names return VW_E_UNSUPPORTED. */
+int32_t vw_set_plan_option(vw_ctx *ctx, const char *name, int64_t value);
+
 /* Page-locked host memory for the HOST-pointer entry points.  They accept any host memory, but copies to and
  * from pageable memory go through the runtime's bounce buffers at a fraction of the PCIe rate; buffers obtained
  * here are copied by DMA directly.  (No counterpart in the reference: a Java caller wraps the address in a
@@ -367,7 +378,11 @@ int32_t vw_swt_universal_threshold_batch_dev(vw_ctx *ctx, const double *coeffs_d
  * number of entries of each band; with indices/values given, the entries of band (r, j) are written at
  * offsets[r*levels + j] (the caller's exclusive prefix sum of the counts, B*levels + 1 entries, the last
  * one the total).  The approximation band stays
- * dense, as in the reference.  The _dev variant takes device pointers for everything. */
+ * dense, as in the reference.  The fill pass never writes at or beyond offsets[band + 1]: if a band holds
+ * more entries than its slot (the coefficients or the threshold differ from the counting pass) the surplus
+ * is dropped and the host variant returns VW_E_LENGTH_MISMATCH; in the fill pass `counts`, if not NULL,
+ * receives the number of entries each band really holds, which is how a _dev caller detects the same
+ * condition.  The _dev variant takes device pointers for everything. */
 int32_t vw_swt_sparsify_batch(vw_ctx *ctx, const double *coeffs, int64_t b, int64_t n, int32_t levels,
                               double threshold, int64_t *counts, const int64_t *offsets, int32_t *indices,
                               double *values);

@@ -19,3 +19,12 @@ def ctx():
     c = N.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def plan(ctx):
+    """Set plan options (vw_set_plan_option) for one test; all of them are reset afterwards."""
+    def set_option(name, value):
+        ctx.set_plan_option(name, value)
+    yield set_option
+    ctx.set_plan_option("reset", 0)

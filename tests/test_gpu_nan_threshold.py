@@ -1,0 +1,85 @@
+"""NaN operands of the threshold rules.  The reference thresholds in two forms that agree on ordinary numbers and
+differ on NaN: MutableMultiLevelMODWTResult.applyThreshold tests `|c| > thr` first (a NaN comparison zeroes the
+coefficient; modwt/MutableMultiLevelMODWTResult.java:97-114), WaveletDenoiser.applyThreshold and
+VectorOps.Denoising.softThreshold test `|c| <= thr` first (a NaN comparison lets the NaN through;
+denoising/WaveletDenoiser.java:554-559, internal/VectorOps.java:454-459).  Neither WaveletOperations.softThreshold
+nor denoiseFixed rejects a NaN threshold (`threshold < 0` is false for NaN).  No reference test holds values for
+these cases: the oracle follows the cited lines, and the GPU must follow the oracle bit for bit -- with every NaN
+counted as the same value, as Java's Double.doubleToLongBits does (sign and payload of a NaN that arithmetic
+produces are the processor's choice, not the language's)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+from util import P, Z, _vp, assert_bits_equal, dev_wavelet_denoise, gpu_denoise, signals
+from vectorwave_amd import _native as N
+from vectorwave_amd.wavelets import get_wavelet
+
+
+def canon(a):
+    """Collapse every NaN to the canonical one (Double.doubleToLongBits)."""
+    a = np.array(a, dtype=np.float64, copy=True)
+    a[np.isnan(a)] = np.nan
+    return a
+
+
+def test_oracle_forms_differ_only_on_nan():
+    c = np.array([1.5, -2.0, 0.0, -0.0, 0.25, np.nan, -np.nan])
+    for thr in (0.0, 0.5, 3.0):
+        assert_bits_equal(o.apply_threshold(c[:5], thr, True), o.soft_threshold(c[:5], thr), "finite operands")
+    assert np.array_equal(o.apply_threshold(c, 0.5, True)[5:], [0.0, 0.0])   # `>`-first form zeroes a NaN coefficient
+    assert np.all(np.isnan(o.soft_threshold(c, 0.5)[5:]))                      # `<=`-first form keeps it
+    assert np.array_equal(o.apply_threshold(c[:5], np.nan, True), np.zeros(5))
+    assert np.all(np.isnan(o.soft_threshold(c[:5], np.nan)))
+    # hard rule: |c| <= NaN is false -> the coefficient stays, in every caller
+    assert_bits_equal(o.apply_threshold(c[:5], np.nan, False), c[:5], "hard, NaN threshold")
+    assert_bits_equal(o.hard_threshold(c[:5], np.nan), c[:5], "hard, NaN threshold")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("soft", [True, False])
+def test_wavelet_operations_threshold_nan(ctx, soft):
+    c = signals(1, 3000, seed=4)[0]
+    c[[3, 700, 2999]] = [np.nan, -np.nan, np.inf]
+    for thr in (np.nan, 0.3):
+        out = np.full_like(c, 9.0)
+        st = ctx.lib.vw_threshold(ctx.handle, _vp(c), c.size, float(thr), 1 if soft else 0, _vp(out))
+        assert st == N.VW_OK, ctx.last_error()
+        want = o.soft_threshold(c, thr) if soft else o.hard_threshold(c, thr)
+        assert_bits_equal(canon(out), canon(want), "vw_threshold soft=%s thr=%r" % (soft, thr))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("soft", [True, False])
+def test_denoise_fixed_nan_threshold(ctx, mode, soft):
+    """WaveletDenoiser.denoiseFixed(x, NaN, type): soft propagates NaN into every output sample, hard keeps every
+    coefficient (denoising/WaveletDenoiser.java:350-360)."""
+    import torch
+    w = get_wavelet("db4")
+    x = signals(3, 777, seed=8)
+    st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, soft, mode, fixed_threshold=float("nan"))
+    assert st == 0
+    got, _ = dev_wavelet_denoise(ctx, torch.from_numpy(x).cuda(), "db4", 0, mode, N.VW_THRESHOLD_FIXED, soft,
+                                 fixed_threshold=float("nan"))
+    assert np.array_equal(np.isnan(got.cpu().numpy()), np.isnan(want)), "NaN pattern"
+    if not soft:
+        assert_bits_equal(canon(got.cpu().numpy()), canon(want), "hard rule with a NaN threshold keeps the coefficients")
+    else:
+        assert np.all(np.isnan(want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("soft", [True, False])
+def test_swt_adapter_nan_threshold(ctx, soft):
+    """VectorWaveSwtAdapter.denoise(x, J, NaN, soft): `NaN < 0` is false, so NaN is used as a fixed threshold through
+    MutableMultiLevelMODWTResult.applyThreshold: soft zeroes every detail, hard keeps them."""
+    w = get_wavelet("db4")
+    x = signals(2, 1000, seed=2)
+    st, want = o.swt_denoise_batch(x, w, 3, float("nan"), soft, P)
+    assert st == 0 and not np.any(np.isnan(want))
+    st, got, _ = gpu_denoise(ctx, x, "db4", 3, P, float("nan"), soft)
+    assert st == N.VW_OK, ctx.last_error()
+    assert_bits_equal(got, want, "swt denoise with a NaN threshold, soft=%s" % soft)

@@ -59,14 +59,15 @@ def test_multilevel_forward_inverse_bit_exact(ctx, wn, n, j, b, mode):
 @pytest.mark.parametrize("wn,n,j,b,tile", [("db4", 16384, 6, 3, None), ("db4", 16390, 6, 2, "2,1"), ("haar", 9000, 8, 2, "1,1"),
                                            ("sym4", 20000, 5, 2, None), ("bior2.2", 12288, 6, 2, "2,1"),
                                            ("db2", 40000, 7, 1, "4,1"), ("db4", 5121, 5, 3, "1,1")])
-def test_streaming_runs_bit_exact(ctx, monkeypatch, wn, n, j, b, tile, wgs, mode):
+def test_streaming_runs_bit_exact(ctx, plan, wn, n, j, b, tile, wgs, mode):
     """The tile-streaming kernels: one workgroup walks several consecutive tiles of a row and carries
-    the level histories in LDS.  VW_STREAM_WGS (wanted workgroups per launch) is lowered so that small
+    the level histories in LDS.  The plan option stream_wgs (wanted workgroups per launch) is lowered so that small
     batches exercise whole-row runs (1), runs that start mid-row (6) and short runs (24)."""
-    monkeypatch.setenv("VW_STREAM_WGS", str(wgs))
+    plan("stream_wgs", wgs)
     if tile:
-        monkeypatch.setenv("VW_FWD_TILE", tile)
-        monkeypatch.setenv("VW_INV_TILE", tile)
+        ppt, hpt = (int(v) for v in tile.split(","))
+        plan("fwd_tile", ppt * 100 + hpt)
+        plan("inv_tile", ppt * 100 + hpt)
     w = get_wavelet(wn)
     x = signals(b, n, seed=n + j + wgs)
     st, want = o.decompose_batch(x, w, j, mode)
@@ -96,11 +97,11 @@ def test_streaming_runs_bit_exact(ctx, monkeypatch, wn, n, j, b, tile, wgs, mode
 @pytest.mark.parametrize("chunks", [1, 3, 1000])
 @pytest.mark.parametrize("wn,n,j,b", [("sym8", 20000, 8, 2), ("db10", 30001, 8, 1), ("coif3", 12288, 7, 2), ("db20", 9000, 6, 2),
                                       ("sym8", 3000, 7, 3), ("bior4.4", 10000, 8, 2)])
-def test_long_context_streaming_bit_exact(ctx, monkeypatch, wn, n, j, b, chunks, mode):
+def test_long_context_streaming_bit_exact(ctx, plan, wn, n, j, b, chunks, mode):
     """Level groups whose context exceeds one chunk run the long-context streaming kernel: runs of tiles
-    warmed up by tiles computed with the stores off.  VW_SDRY_CHUNKS sets the run length: 1 (every tile
+    warmed up by tiles computed with the stores off.  The plan option sdry_chunks sets the run length: 1 (every tile
     warms up on its own), 3 (runs start mid-row), 1000 (whole rows; the warm-up wraps around the row)."""
-    monkeypatch.setenv("VW_SDRY_CHUNKS", str(chunks))
+    plan("sdry_chunks", chunks)
     w = get_wavelet(wn)
     x = signals(b, n, seed=n + j + chunks)
     st, want = o.decompose_batch(x, w, j, mode)

@@ -194,11 +194,11 @@ def test_c_abi_argument_checks(ctx):
     assert ctx.lib.vw_stream_state_destroy(ctx.handle, state) == N.VW_OK
 
 
-@pytest.mark.parametrize("hook", ["VW_NO_REG_SELECT", "VW_NO_STD_CHAINS"])
-def test_long_row_kernels_on_short_rows(ctx, monkeypatch, hook):
+@pytest.mark.parametrize("hook", ["no_reg_select", "no_std_chains"])
+def test_long_row_kernels_on_short_rows(ctx, plan, hook):
     # the 256-lane LDS kernels normally serve rings and blocks beyond 2048 samples; the hooks route short rows
     # through them too, so their whole logic is exercised on the shapes the oracle checks quickly
-    monkeypatch.setenv(hook, "1")
+    plan(hook, 1)
     for est in (o.NOISE_MAD, o.NOISE_STD):
         for mult in (1.0, 1.5):
             _run_and_compare(ctx, "db4", 3, 300, 128, 3, P, o.UNIVERSAL, True, mult, est, seed=est + 10)

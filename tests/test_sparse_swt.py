@@ -121,3 +121,49 @@ def test_gpu_sparse_argument_checks(ctx):
     want[0, 3] = 5.0
     assert np.array_equal(out[0, :2], want) and np.all(out[0, 2] == 7.0)
     assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), 1, 8, 0, 0.5, vp(offs), None, None, None) == N.VW_E_LEVEL
+
+
+@pytest.mark.gpu
+def test_fill_pass_with_a_lower_threshold_stays_inside_its_slots(ctx):
+    """Offsets sized by a counting pass at one threshold, fill pass at a lower one: every band then holds more
+    entries than its slot.  Nothing may be written at or beyond offsets[band + 1] (the last band's slot ends the
+    caller's buffers), the call reports the mismatch, and the _dev form tells the real counts."""
+    import torch
+    from vectorwave_amd import _native as N
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    b, n, levels = 3, 3000, 2
+    rng = np.random.default_rng(5)
+    coeffs = rng.standard_normal((b, levels + 1, n))
+    hi_thr, lo_thr = 1.5, 0.2
+    counts = np.zeros(b * levels, dtype=np.int64)
+    assert ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), b, n, levels, hi_thr, vp(counts), None, None, None) == N.VW_OK
+    offsets = np.zeros(b * levels + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    guard = 4096
+    idx = np.full(total + guard, -7, dtype=np.int32)
+    val = np.full(total + guard, -7.0)
+    st = ctx.lib.vw_swt_sparsify_batch(ctx.handle, vp(coeffs), b, n, levels, lo_thr, None, vp(offsets), vp(idx), vp(val))
+    assert st == N.VW_E_LENGTH_MISMATCH and "entries" in ctx.last_error()
+    assert np.all(idx[total:] == -7) and np.all(val[total:] == -7.0)
+    # what was written is the head of each band's entry list at the lower threshold
+    for k in range(b * levels):
+        wi, wv = o.sparse_vector(coeffs[k // levels, k % levels], lo_thr)
+        room = int(offsets[k + 1] - offsets[k])
+        assert np.array_equal(idx[offsets[k]:offsets[k + 1]], wi[:room])
+        assert np.array_equal(val[offsets[k]:offsets[k + 1]], wv[:room])
+    # device form: guard region behind the buffers untouched, counts_dev receives the real numbers
+    c_t = torch.from_numpy(coeffs).cuda()
+    off_t = torch.from_numpy(offsets).cuda()
+    idx_t = torch.full((total + guard,), -7, dtype=torch.int32, device="cuda")
+    val_t = torch.full((total + guard,), -7.0, dtype=torch.float64, device="cuda")
+    cnt_t = torch.full((b * levels,), -1, dtype=torch.int64, device="cuda")
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = ctx.lib.vw_swt_sparsify_batch_dev(ctx.handle, C.c_void_p(c_t.data_ptr()), b, n, levels, lo_thr, C.c_void_p(cnt_t.data_ptr()),
+                                           C.c_void_p(off_t.data_ptr()), C.c_void_p(idx_t.data_ptr()), C.c_void_p(val_t.data_ptr()), sp)
+    assert st == N.VW_OK
+    torch.cuda.synchronize()
+    assert bool((idx_t[total:] == -7).all()) and bool((val_t[total:] == -7.0).all())
+    real = [o.sparse_vector(coeffs[k // levels, k % levels], lo_thr)[0].size for k in range(b * levels)]
+    assert cnt_t.cpu().tolist() == real
+    assert np.array_equal(idx_t[:total].cpu().numpy(), idx[:total])

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the tuning build (make -C vectorwave_amd/csrc tuning): only that build reads the VW_* overrides
+export VW_LIBVWGPU=${VW_LIBVWGPU:-/root/repo/vectorwave_amd/libvwgpu_tuning.so}
 # effective clock (GRBM_GUI_ACTIVE / 8 / duration) of the fused kernels under the ablations
 cd /tmp && export TMPDIR=/tmp
 for ab in none nostore nocompute; do

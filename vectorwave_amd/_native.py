@@ -56,6 +56,7 @@ SIGNATURES = {
     "vw_last_error": (C.c_char_p, [_vp]),
     "vw_performance_info": (C.c_char_p, [_vp]),
     "vw_synchronize": (C.c_int32, [_vp]),
+    "vw_set_plan_option": (C.c_int32, [_vp, C.c_char_p, C.c_int64]),
     "vw_device_count": (C.c_int32, []),
     "vw_max_levels": (C.c_int32, [C.c_int64, C.c_int32]),
     "vw_modwt_forward_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
@@ -177,6 +178,34 @@ def load():
     return lib
 
 
+class _ContextState:
+    """What the finalizers of page-locked arrays share with their Context: the native handle stays alive until
+    both the Context has been closed and the last such array has been released, whichever comes last, so that
+    vw_host_free never sees a destroyed context and an array never outlives its memory."""
+
+    def __init__(self, lib, handle):
+        self.lib = lib
+        self.handle = handle
+        self.outstanding = 0
+        self.closed = False
+
+    def release_pinned(self, address):
+        if self.handle is None:
+            return
+        self.lib.vw_host_free(self.handle, C.c_void_p(address))
+        self.outstanding -= 1
+        self._maybe_destroy()
+
+    def close(self):
+        self.closed = True
+        self._maybe_destroy()
+
+    def _maybe_destroy(self):
+        if self.closed and self.outstanding == 0 and self.handle is not None:
+            self.lib.vw_destroy(self.handle)
+            self.handle = None
+
+
 class Context:
     """One vw_ctx: a HIP device plus the library-owned staging buffers and stream."""
 
@@ -190,6 +219,7 @@ class Context:
                 "vectorwave_amd has no CPU fallback." % (device, st))
         self.handle = h
         self.device = device
+        self._state = _ContextState(self.lib, h)
 
     def last_error(self) -> str:
         return self.lib.vw_last_error(self.handle).decode()
@@ -197,9 +227,30 @@ class Context:
     def performance_info(self) -> str:
         return self.lib.vw_performance_info(self.handle).decode()
 
+    def set_plan_option(self, name: str, value: int) -> None:
+        """vw_set_plan_option: choose among equivalent launch plans (tests and tuning); 'reset' restores defaults."""
+        st = self.lib.vw_set_plan_option(self.handle, name.encode(), int(value))
+        if st != VW_OK:
+            raise ValueError(self.last_error())
+
+    def plan_options(self, **options):
+        """Context manager: apply plan options for the duration of a `with` block, then reset all of them."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            try:
+                for k, v in options.items():
+                    self.set_plan_option(k, v)
+                yield self
+            finally:
+                self.set_plan_option("reset", 0)
+        return scope()
+
     def host_array(self, shape, dtype="float64"):
         """A NumPy array over page-locked host memory (vw_host_alloc): the host-pointer entry points copy such
-        buffers by DMA at the PCIe rate.  The memory is released when the array is garbage-collected."""
+        buffers by DMA at the PCIe rate.  The memory is released when the array is garbage-collected; a Context
+        closed before that keeps its native handle until the last such array is gone."""
         import numpy as np
         dt = np.dtype(dtype)
         count = int(np.prod(shape))
@@ -211,18 +262,21 @@ class Context:
             raise MemoryError(self.last_error())
         buf = (C.c_char * (count * dt.itemsize)).from_address(ptr.value)
         arr = np.frombuffer(buf, dtype=dt).reshape(shape)
-        lib, handle, address = self.lib, self.handle, ptr.value
+        state, address = self._state, ptr.value
+        state.outstanding += 1
         import weakref
-        weakref.finalize(buf, lambda: lib.vw_host_free(handle, C.c_void_p(address)))
+        weakref.finalize(buf, state.release_pinned, address)
         return arr
 
     def synchronize(self):
         return self.lib.vw_synchronize(self.handle)
 
     def close(self):
-        if self.handle is not None and self.handle.value:
-            self.lib.vw_destroy(self.handle)
+        """Release the context.  Further calls through this object fail; the native handle itself is destroyed
+        once no page-locked array obtained from host_array() is alive any more."""
+        if self.handle is not None:
             self.handle = None
+            self._state.close()
 
     def __del__(self):
         try:

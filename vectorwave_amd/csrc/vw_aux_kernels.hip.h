@@ -1159,6 +1159,10 @@ __global__ void __launch_bounds__(kThreads) k_transpose(const double* __restrict
 // One workgroup per detail band (row, level).  Pass 1 (indices == nullptr) counts the entries with
 // |v| > threshold; pass 2 writes them in index order at offsets[band]: every lane owns four consecutive
 // elements of a 1024-element chunk, a workgroup prefix sum of the lanes' counts gives each lane its place.
+// Pass 2 never writes at or beyond offsets[band + 1]: when the band holds more entries than the caller's
+// prefix sum left room for (a different threshold or different coefficients than in pass 1), the surplus is
+// dropped, and the number of entries the band really holds goes to counts[band] (if given) so that the caller
+// can tell.
 
 struct SparsifyArgs {
     const double* coeffs;  // band (r, j) at coeffs + r*row_stride + j*band_stride
@@ -1166,8 +1170,8 @@ struct SparsifyArgs {
     int64_t n;
     int32_t levels;
     double threshold;
-    int64_t* counts;         // [rows * levels] (pass 1)
-    const int64_t* offsets;  // [rows * levels] (pass 2)
+    int64_t* counts;         // [rows * levels]: pass 1 result; optional in pass 2 (entries found)
+    const int64_t* offsets;  // [rows * levels + 1] (pass 2)
     int32_t* indices;        // pass 2
     double* values;          // pass 2
 };
@@ -1193,7 +1197,8 @@ __global__ void __launch_bounds__(kThreads) k_sparsify(const SparsifyArgs a) {
         if (tid == 0) a.counts[band] = static_cast<int64_t>(red[0]);
         return;
     }
-    int64_t run = a.offsets[band];
+    const int64_t start = a.offsets[band], end = a.offsets[band + 1];
+    int64_t run = start;
     for (int64_t base = 0; base < n; base += 4 * kThreads) {
         const int64_t i0 = base + 4 * tid;
         double v[4];
@@ -1218,13 +1223,16 @@ __global__ void __launch_bounds__(kThreads) k_sparsify(const SparsifyArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (keep[k]) {
-                a.indices[pos] = static_cast<int32_t>(i0 + k);
-                a.values[pos] = v[k];
+                if (pos < end) {
+                    a.indices[pos] = static_cast<int32_t>(i0 + k);
+                    a.values[pos] = v[k];
+                }
                 ++pos;
             }
         run += total;
         __syncthreads();
     }
+    if (tid == 0 && a.counts != nullptr) a.counts[band] = run - start;
 }
 
 struct DensifyArgs {

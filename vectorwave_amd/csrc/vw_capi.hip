@@ -15,7 +15,6 @@
 #include <string.h>
 
 #include <mutex>
-#include <vector>
 
 #include "../../include/vwgpu.h"
 
@@ -30,6 +29,26 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// Choices among equivalent launch plans (tile shape, run lengths, kernel family).  Every setting produces the
+// same bits; the defaults are the measured-best ones.  Set through vw_set_plan_option (tests exercise the
+// rarely-taken plans on small inputs with it); the product library never reads the environment.
+struct PlanOptions {
+    int fwd_tile_p = 0, fwd_tile_h = 0;  // forced forward tile shape (chunks per tile, halo chunks); 0 = planner's choice
+    int inv_tile_p = 0, inv_tile_h = 0;
+    int64_t fwd_chunks = 0;              // cap on the tiles per run of the streaming forward; 0 = default
+    int64_t stream_wgs = 0;              // workgroups wanted per streaming launch; 0 = default
+    int64_t sdry_chunks = 0;             // run length of the long-context kernels; 0 = default
+    int no_sdry = 0;                     // 1: never use the long-context kernels
+    int nt_stores = -1;                  // -1 by launch size, 0/1 forced
+    int no_unroll = 0;                   // 1: generic tap loop also for 8+8-tap filters
+    int no_reg_select = 0;               // 1: LDS/global selection kernels also for short rows
+    int no_std_chains = 0;               // 1: plain reduction kernel for the streaming STD
+    int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
+#ifdef VW_TUNING
+    char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
+#endif
+};
+
 struct vw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -41,7 +60,9 @@ struct vw_ctx {
     DevBuf stage_out;   // ... and of the output
     DevBuf denoise_ws;  // coefficient block for vw_swt_denoise_batch(_dev) when the caller passes none
     DevBuf cell;        // 8-byte first_bad cell for host-pointer entry points
+    DevBuf ws_borrow;   // set (under mu) by an entry point that may not allocate: stands in for `ws`, never freed
     int lds_limit = 65536;
+    PlanOptions opt;
 };
 
 static int set_err(vw_ctx* ctx, int code, const char* fmt, ...) {
@@ -76,6 +97,85 @@ static int ensure(vw_ctx* ctx, DevBuf& b, size_t bytes) {
     return VW_OK;
 }
 
+// The context's ping-pong plane, or the stand-in an allocation-free entry point has lent for this call.
+static int ensure_ws(vw_ctx* ctx, size_t bytes, double** out) {
+    if (ctx->ws_borrow.p != nullptr) {
+        if (ctx->ws_borrow.bytes < bytes)
+            return set_err(ctx, VW_E_WORKSPACE, "this plan needs a %zu-byte intermediate plane, %zu bytes of static scratch are left for it",
+                           bytes, ctx->ws_borrow.bytes);
+        *out = static_cast<double*>(ctx->ws_borrow.p);
+        return VW_OK;
+    }
+    const int rc = ensure(ctx, ctx->ws, bytes);
+    *out = static_cast<double*>(ctx->ws.p);
+    return rc;
+}
+
+static bool parse_pair(int64_t v, int* p, int* h) {
+    // tile shapes travel as ppt * 100 + hpt (e.g. 401 = 4 chunks per tile, 1 halo chunk); 0 clears
+    if (v < 0 || v > 99999) return false;
+    *p = static_cast<int>(v / 100);
+    *h = static_cast<int>(v % 100);
+    return true;
+}
+
+extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t value) {
+    if (ctx == nullptr) return VW_E_NULL;
+    if (name == nullptr) return set_err(ctx, VW_E_NULL, "option name cannot be null");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    PlanOptions& o = ctx->opt;
+    if (strcmp(name, "reset") == 0) {
+        o = PlanOptions();
+    } else if (strcmp(name, "fwd_tile") == 0) {
+        if (!parse_pair(value, &o.fwd_tile_p, &o.fwd_tile_h)) return set_err(ctx, VW_E_UNSUPPORTED, "bad tile shape %lld", static_cast<long long>(value));
+    } else if (strcmp(name, "inv_tile") == 0) {
+        if (!parse_pair(value, &o.inv_tile_p, &o.inv_tile_h)) return set_err(ctx, VW_E_UNSUPPORTED, "bad tile shape %lld", static_cast<long long>(value));
+    } else if (strcmp(name, "fwd_chunks") == 0) {
+        o.fwd_chunks = value;
+    } else if (strcmp(name, "stream_wgs") == 0) {
+        o.stream_wgs = value;
+    } else if (strcmp(name, "sdry_chunks") == 0) {
+        o.sdry_chunks = value;
+    } else if (strcmp(name, "no_sdry") == 0) {
+        o.no_sdry = value != 0;
+    } else if (strcmp(name, "nt_stores") == 0) {
+        o.nt_stores = value < 0 ? -1 : (value != 0);
+    } else if (strcmp(name, "no_unroll") == 0) {
+        o.no_unroll = value != 0;
+    } else if (strcmp(name, "no_reg_select") == 0) {
+        o.no_reg_select = value != 0;
+    } else if (strcmp(name, "no_std_chains") == 0) {
+        o.no_std_chains = value != 0;
+    } else if (strcmp(name, "no_row_denoise") == 0) {
+        o.no_row_denoise = value != 0;
+    } else {
+        return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
+    }
+    return VW_OK;
+}
+
+#ifdef VW_TUNING
+// Tuning build (tools/ only, never shipped as libvwgpu.so): the plan options can also come from the environment,
+// and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
+static void tuning_env(vw_ctx* ctx) {
+    static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
+                                        "no_reg_select", "no_std_chains", "no_row_denoise"};
+    for (const char* nm : names) {
+        char env[64] = "VW_";
+        size_t k = 3;
+        for (const char* c = nm; *c != 0 && k + 1 < sizeof(env); ++c) env[k++] = static_cast<char>(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        env[k] = 0;
+        if (const char* e = getenv(env)) (void)vw_set_plan_option(ctx, nm, atoll(e));
+    }
+    for (int inv = 0; inv < 2; ++inv)
+        if (const char* e = getenv(inv ? "VW_INV_TILE" : "VW_FWD_TILE")) {
+            int p = 0, h = 0;
+            if (sscanf(e, "%d,%d", &p, &h) == 2) (void)vw_set_plan_option(ctx, inv ? "inv_tile" : "fwd_tile", p * 100 + h);
+        }
+    if (const char* e = getenv("VW_ABLATE")) snprintf(ctx->opt.ablate, sizeof(ctx->opt.ablate), "%s", e);
+}
+#endif
+
 extern "C" int32_t vw_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -108,6 +208,10 @@ extern "C" int32_t vw_init(int32_t device, vw_ctx** out_ctx) {
         snprintf(ctx->info, sizeof(ctx->info), "HIP device %d", device);
     }
     strcpy(ctx->err, "no error");
+#ifdef VW_TUNING
+    tuning_env(ctx);
+    strncat(ctx->info, " [TUNING BUILD: ablation hooks enabled]", sizeof(ctx->info) - strlen(ctx->info) - 1);
+#endif
     *out_ctx = ctx;
     return VW_OK;
 }
@@ -196,13 +300,11 @@ static CfgList inv_cfgs(bool fma) {
     return CfgList{fma ? kInvCfgsFma : kInvCfgs, n, true};
 }
 
-// Tuning hook: VW_FWD_TILE / VW_INV_TILE = "<ppt>,<hpt>" force an instantiated tile shape
-// (ignored when the halo does not fit it).
-static bool env_cfg(const CfgList& cl, int hpt_need, TileCfg* out) {
-    const char* e = getenv(cl.inverse ? "VW_INV_TILE" : "VW_FWD_TILE");
-    if (e == nullptr) return false;
-    int p = 0, h = 0;
-    if (sscanf(e, "%d,%d", &p, &h) != 2) return false;
+// Plan option fwd_tile / inv_tile: force an instantiated tile shape (ignored when the halo does not fit it).
+static bool forced_cfg(const PlanOptions& opt, const CfgList& cl, int hpt_need, TileCfg* out) {
+    const int p = cl.inverse ? opt.inv_tile_p : opt.fwd_tile_p;
+    const int h = cl.inverse ? opt.inv_tile_h : opt.fwd_tile_h;
+    if (p <= 0 || h <= 0) return false;
     for (int i = 0; i < cl.n; ++i)
         if (cl.v[i].ppt == p && cl.v[i].hpt == h && h >= hpt_need) {
             *out = cl.v[i];
@@ -211,11 +313,12 @@ static bool env_cfg(const CfgList& cl, int hpt_need, TileCfg* out) {
     return false;
 }
 
-static bool pick_cfg(int64_t n, int64_t halo, int lds_limit, const CfgList& cl, TileCfg* out) {
+static bool pick_cfg(const vw_ctx* ctx, int64_t n, int64_t halo, const CfgList& cl, TileCfg* out) {
+    const int lds_limit = ctx->lds_limit;
     // two samples of slack: pair alignment may start a pair one sample outside the exact need
     int hpt_need = static_cast<int>((halo + 2 + kChunk - 1) / kChunk);
     if (hpt_need < 1) hpt_need = 1;
-    if (env_cfg(cl, hpt_need, out)) return true;
+    if (forced_cfg(ctx->opt, cl, hpt_need, out)) return true;
     // smallest instantiated halo that covers the need and fits LDS
     int hpt = 0;
     for (int i = 0; i < cl.n; ++i) {
@@ -269,6 +372,16 @@ struct Step {
     int32_t hoff[kMaxLevels + 2] = {0}, hlen[kMaxLevels + 2] = {0};
 };
 
+// at most one step per level; fixed storage so that planning never touches the heap
+struct StepList {
+    Step v[kMaxLevels + 1];
+    int count = 0;
+    void push_back(const Step& s) { v[count++] = s; }
+    bool empty() const { return count == 0; }
+    int size() const { return count; }
+    const Step& operator[](int i) const { return v[i]; }
+};
+
 static void scale_taps(const double* src, int len, double* dst) {
     // MODWTTransform.java:133-142: scale = 1.0 / Math.sqrt(2.0); tap * scale
     const double scale = 1.0 / sqrt(2.0);
@@ -283,7 +396,7 @@ static void scale_taps(const double* src, int len, double* dst) {
 // Streaming forward: split each row into runs of consecutive tiles, one workgroup per run.  Long runs
 // amortise the one halo a run pays for; short runs keep enough workgroups in flight when the batch
 // is small.  VW_FWD_CHUNKS caps the run length (1 = one tile per workgroup, as the halo kernels do).
-static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
+static void plan_stream(const PlanOptions& opt, FwdArgs* a, int64_t rows, int lmax) {
     int off = 0;
     for (int j = a->lev0; j <= a->lev1; ++j) {
         const int64_t hl = (static_cast<int64_t>(lmax - 1) * (static_cast<int64_t>(1) << (j - 1)) + 1) & ~static_cast<int64_t>(1);
@@ -294,17 +407,9 @@ static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
     }
     // runs of at most 6 tiles: whole-row runs are 3 % faster on some buffer placements and 6 % slower on
     // others (every resident workgroup then sweeps its row in lockstep with all the others); 6 is steady
-    int64_t cap = 6;
-    if (const char* e = getenv("VW_FWD_CHUNKS")) {
-        const long v = atol(e);
-        if (v >= 1) cap = v;
-    }
+    const int64_t cap = opt.fwd_chunks >= 1 ? opt.fwd_chunks : 6;
     const int64_t tiles = a->tiles_per_row;
-    int64_t want_wgs = 16384;  // several rounds of resident workgroups on 256 CUs
-    if (const char* e = getenv("VW_STREAM_WGS")) {  // test / tuning hook
-        const long v = atol(e);
-        if (v >= 1) want_wgs = v;
-    }
+    const int64_t want_wgs = opt.stream_wgs >= 1 ? opt.stream_wgs : 16384;  // several rounds of resident workgroups on 256 CUs
     int64_t nseg = rows > 0 ? (want_wgs + rows - 1) / rows : 1;
     if (nseg < 1) nseg = 1;
     if (nseg > tiles) nseg = tiles;
@@ -318,8 +423,9 @@ static void plan_stream(FwdArgs* a, int64_t rows, int lmax) {
 // Long-context streaming (k_fwd_sdry / k_inv_sdry): shape 1 = 512 lanes, 2048-sample tiles, histories up to 2046
 // samples per level; shape 2 = 512 lanes, 4096-sample tiles, histories up to 2558.  Returns 0 if the
 // level group does not fit either.
-static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, int32_t* hoff, int32_t* hlen, int* ndry,
+static int plan_sdry(const vw_ctx* ctx, int lev0, int lev1, int lmax, bool inverse, int32_t* hoff, int32_t* hlen, int* ndry,
                      int* hist_cap) {
+    const int lds_limit = ctx->lds_limit;
     int64_t sum = 0, hmax = 0;
     for (int j = lev0; j <= lev1; ++j) {
         const int64_t hl = (static_cast<int64_t>(lmax - 1) * (static_cast<int64_t>(1) << (j - 1)) + 1) & ~static_cast<int64_t>(1);
@@ -329,7 +435,7 @@ static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, 
         sum += hl;
         if (hl > hmax) hmax = hl;
     }
-    if (getenv("VW_NO_SDRY") != nullptr) return 0;
+    if (ctx->opt.no_sdry) return 0;
     for (int v = 1; v <= 2; ++v) {
         const SdryShape& sh = kSdry[v];
         const int64_t halo = static_cast<int64_t>(sh.hb) * kChunk;
@@ -346,8 +452,8 @@ static int plan_sdry(int lev0, int lev1, int lmax, int lds_limit, bool inverse, 
 }
 
 // Run length of the long-context kernels: long enough to amortise the warm-up tiles, short enough to
-// fill the chip.  VW_SDRY_CHUNKS overrides (test / tuning hook).
-static void sdry_runs(int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out) {
+// fill the chip.  Plan option sdry_chunks overrides.
+static void sdry_runs(const PlanOptions& opt, int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out) {
     // about 1024 runs in all: two 512-lane workgroups fit a CU, and longer runs amortise the warm-up tiles better
     // than a third and fourth wave of workgroups would (sym8 J=8 on 64 x 777777: 24-48 tiles per run measured best)
     int64_t nseg = rows > 0 ? (1024 + rows - 1) / rows : 1;
@@ -356,19 +462,16 @@ static void sdry_runs(int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, i
     int64_t nch = (tiles + nseg - 1) / nseg;
     const int64_t min_run = static_cast<int64_t>(ndry) * 6;
     if (nch < min_run) nch = min_run < tiles ? min_run : tiles;
-    if (const char* e = getenv("VW_SDRY_CHUNKS")) {
-        const long v = atol(e);
-        if (v >= 1) nch = v < tiles ? v : tiles;
-    }
+    if (opt.sdry_chunks >= 1) nch = opt.sdry_chunks < tiles ? opt.sdry_chunks : tiles;
     if (nch < 1) nch = 1;
     *nchunks = static_cast<int32_t>(nch);
     *nseg_out = static_cast<int32_t>((tiles + nch - 1) / nch);
 }
 
 // Launches that move more than 1 GiB (four times the last-level cache) store their results with the streaming
-// hint; smaller ones leave them cacheable for the kernel that reads them next.  VW_NT_STORES=0/1 overrides.
-static int streaming_stores(int64_t b, int64_t n, int levels) {
-    if (const char* e = getenv("VW_NT_STORES")) return atoi(e) != 0;
+// hint; smaller ones leave them cacheable for the kernel that reads them next.  Plan option nt_stores overrides.
+static int streaming_stores(const PlanOptions& opt, int64_t b, int64_t n, int levels) {
+    if (opt.nt_stores >= 0) return opt.nt_stores != 0;
     return static_cast<double>(b) * static_cast<double>(n) * 8.0 * (levels + 2) > 1073741824.0;
 }
 
@@ -439,7 +542,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
     }
 
     // ---- plan ----------------------------------------------------------------
-    std::vector<Step> steps;
+    StepList steps;
     // a context beyond one chunk: all levels in one pass of the long-context streaming kernel if it fits
     if (!generic_all && fwd_halo(1, levels, lh, lg, nullptr) + 2 > kChunk) {
         Step st;
@@ -447,7 +550,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
         st.lev1 = levels;
         st.fused = true;
         st.cfg = TileCfg{0, 0, kThreads};
-        st.sdry = plan_sdry(1, levels, lh > lg ? lh : lg, ctx->lds_limit, false, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
+        st.sdry = plan_sdry(ctx, 1, levels, lh > lg ? lh : lg, false, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
         if (st.sdry != 0) steps.push_back(st);
     }
     if (steps.empty()) {
@@ -461,14 +564,14 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             if (!generic_all) {
                 int hi = j;
                 TileCfg cfg;
-                if (pick_cfg(n, fwd_halo(j, j, lh, lg, nullptr), ctx->lds_limit, fwd_cfgs(), &cfg)) {
+                if (pick_cfg(ctx, n, fwd_halo(j, j, lh, lg, nullptr), fwd_cfgs(), &cfg)) {
                     st.fused = true;
                     st.cfg = cfg;
                     while (hi + 1 <= levels) {
                         TileCfg c2;
                         const int64_t hneed = fwd_halo(j, hi + 1, lh, lg, nullptr);
                         if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
-                        if (!pick_cfg(n, hneed, ctx->lds_limit, fwd_cfgs(), &c2)) break;
+                        if (!pick_cfg(ctx, n, hneed, fwd_cfgs(), &c2)) break;
                         st.cfg = c2;
                         ++hi;
                     }
@@ -480,11 +583,11 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
         }
     }
     const int nsteps = static_cast<int>(steps.size());
+    double* wsp = nullptr;
     if (nsteps > 1) {
-        const int rc = ensure(ctx, ctx->ws, static_cast<size_t>(b) * n * 8);
+        const int rc = ensure_ws(ctx, static_cast<size_t>(b) * n * 8, &wsp);
         if (rc != VW_OK) return rc;
     }
-    double* wsp = static_cast<double*>(ctx->ws.p);
 
     // ---- run -----------------------------------------------------------------
     const double* in = x;
@@ -520,14 +623,14 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             const int T = kSdry[st.sdry].tile();
             const int64_t tiles = (n + T - 1) / T;
             a.tiles_per_row = static_cast<int32_t>(tiles);
-            sdry_runs(b, tiles, st.ndry, &a.nchunks, &a.ntiles);
+            sdry_runs(ctx->opt, b, tiles, st.ndry, &a.nchunks, &a.ntiles);
             a.first_bad = first ? first_bad_cell : nullptr;
             a.taps = taps;
-            a.nt_store = streaming_stores(b, n, levels);
-            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
-                if (strstr(dbg, "nostore")) a.n_store = 0;
-                if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
-            }
+            a.nt_store = streaming_stores(ctx->opt, b, n, levels);
+#ifdef VW_TUNING
+            if (strstr(ctx->opt.ablate, "nostore")) a.n_store = 0;
+            if (strstr(ctx->opt.ablate, "nocompute")) a.lh = a.lg = 0;
+#endif
             const bool vec2 = (n % 2 == 0) && (in_stride % 2 == 0) && (vstride % 2 == 0) && aligned16(in) &&
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
@@ -555,11 +658,11 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             a.lev1 = st.lev1;
             a.lh = lh;
             a.lg = lg;
-            if (st.cfg.hpt == 1) plan_stream(&a, b, lh > lg ? lh : lg);
-            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
-                if (strstr(dbg, "nostore")) a.n_store = 0;
-                if (strstr(dbg, "nocompute")) a.lh = a.lg = 0;
-            }
+            if (st.cfg.hpt == 1) plan_stream(ctx->opt, &a, b, lh > lg ? lh : lg);
+#ifdef VW_TUNING
+            if (strstr(ctx->opt.ablate, "nostore")) a.n_store = 0;
+            if (strstr(ctx->opt.ablate, "nocompute")) a.lh = a.lg = 0;
+#endif
             int64_t hn[kMaxLevels + 2] = {0};
             fwd_halo(st.lev0, st.lev1, lh, lg, hn);
             const int64_t halo = static_cast<int64_t>(st.cfg.hpt) * kChunk;
@@ -567,17 +670,18 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                 int64_t ps = halo - hn[j];
                 if (ps < 0) ps = 0;
                 a.pstart[j] = static_cast<int32_t>(ps & ~static_cast<int64_t>(1));
-                if (const char* dbg = getenv("VW_ABLATE"))
-                    if (strstr(dbg, "nohalo")) a.pstart[j] = static_cast<int32_t>(halo);
+#ifdef VW_TUNING
+                if (strstr(ctx->opt.ablate, "nohalo")) a.pstart[j] = static_cast<int32_t>(halo);
+#endif
             }
             a.first_bad = first ? first_bad_cell : nullptr;
             a.taps = taps;
-            a.nt_store = streaming_stores(b, n, levels);
+            a.nt_store = streaming_stores(ctx->opt, b, n, levels);
             const bool vec2 = (n % 2 == 0) && (in_stride % 2 == 0) && (vstride % 2 == 0) && aligned16(in) &&
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
         } else {
             if (first && first_bad_cell != nullptr) {
@@ -718,7 +822,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
     }
     if (generic_all && thr_mode != 0) return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
 
-    std::vector<Step> steps;
+    StepList steps;
     {
         int j = levels;
         while (j >= 1) {
@@ -731,7 +835,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             // long-context streaming kernel
             if (!generic_all && inv_halo(1, j, lhr) + 2 > kChunk) {
                 for (int lo = 1; lo <= j && st.sdry == 0; ++lo) {
-                    st.sdry = plan_sdry(lo, j, lhr, ctx->lds_limit, true, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
+                    st.sdry = plan_sdry(ctx, lo, j, lhr, true, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
                     if (st.sdry != 0) st.lev0 = lo;
                 }
                 if (st.sdry != 0) {
@@ -743,7 +847,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             }
             if (!generic_all) {
                 TileCfg cfg;
-                if (pick_cfg(n, inv_halo(j, j, lhr), ctx->lds_limit, inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg)) {
+                if (pick_cfg(ctx, n, inv_halo(j, j, lhr), inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg)) {
                     st.fused = true;
                     st.cfg = cfg;
                     int lo = j;
@@ -751,7 +855,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                         TileCfg c2;
                         const int64_t hneed = inv_halo(lo - 1, j, lhr);
                         if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
-                        if (!pick_cfg(n, hneed, ctx->lds_limit, inv_cfgs((flags & VW_FLAG_FMA) != 0), &c2)) break;
+                        if (!pick_cfg(ctx, n, hneed, inv_cfgs((flags & VW_FLAG_FMA) != 0), &c2)) break;
                         st.cfg = c2;
                         --lo;
                     }
@@ -763,11 +867,11 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
         }
     }
     const int nsteps = static_cast<int>(steps.size());
+    double* wsp = nullptr;
     if (nsteps > 1) {
-        const int rc = ensure(ctx, ctx->ws, static_cast<size_t>(b) * n * 8);
+        const int rc = ensure_ws(ctx, static_cast<size_t>(b) * n * 8, &wsp);
         if (rc != VW_OK) return rc;
     }
-    double* wsp = static_cast<double*>(ctx->ws.p);
 
     const double* rin = aslot;
     int64_t rin_stride = rowc;
@@ -801,7 +905,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             const int T = kSdry[st.sdry].tile();
             const int64_t tiles = (n + T - 1) / T;
             a.tiles_per_row = static_cast<int32_t>(tiles);
-            sdry_runs(b, tiles, st.ndry, &a.nchunks, &a.ntiles);
+            sdry_runs(ctx->opt, b, tiles, st.ndry, &a.nchunks, &a.ntiles);
             a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
             a.thr_mode = thr_mode;
             a.thr = thr_rows;
@@ -810,11 +914,11 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
-            a.nt_store = streaming_stores(b, n, levels);
-            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
-                if (strstr(dbg, "nostore")) a.n_store = 0;
-                if (strstr(dbg, "nocompute")) a.lh = 0;
-            }
+            a.nt_store = streaming_stores(ctx->opt, b, n, levels);
+#ifdef VW_TUNING
+            if (strstr(ctx->opt.ablate, "nostore")) a.n_store = 0;
+            if (strstr(ctx->opt.ablate, "nocompute")) a.lh = 0;
+#endif
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
@@ -855,13 +959,13 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
-            a.nt_store = streaming_stores(b, n, levels);
-            if (const char* dbg = getenv("VW_ABLATE")) {  // tuning harness only: results are wrong
-                if (strstr(dbg, "nostore")) a.n_store = 0;
-                if (strstr(dbg, "nocompute")) a.lh = 0;
-                if (strstr(dbg, "nohalo"))
-                    for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
-            }
+            a.nt_store = streaming_stores(ctx->opt, b, n, levels);
+#ifdef VW_TUNING
+            if (strstr(ctx->opt.ablate, "nostore")) a.n_store = 0;
+            if (strstr(ctx->opt.ablate, "nocompute")) a.lh = 0;
+            if (strstr(ctx->opt.ablate, "nohalo"))
+                for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
+#endif
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
@@ -1023,14 +1127,14 @@ extern "C" int32_t vw_threshold_dev(vw_ctx* ctx, const double* in_dev, int64_t c
     if (ctx == nullptr) return VW_E_NULL;
     if (count < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "negative count");
     if (count > 0 && (in_dev == nullptr || out_dev == nullptr)) return set_err(ctx, VW_E_NULL, "Coefficients array cannot be null");
-    if (threshold < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold must be non-negative");
+    if (threshold < 0) return set_err(ctx, VW_E_NOT_POSITIVE, "Threshold must be non-negative");  // NaN passes, as in the reference
     if (count == 0) return VW_OK;
     VW_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int64_t blocks = (count + kThreads - 1) / kThreads;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_threshold, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, in_dev, out_dev, count,
-                       threshold, soft ? 1 : 2);
+                       threshold, soft ? 3 : 2);
     VW_HIP(ctx, hipGetLastError());
     return VW_OK;
 }
@@ -1060,8 +1164,8 @@ extern "C" int32_t vw_threshold(vw_ctx* ctx, const double* in, int64_t count, do
 static double host_sqrt_2_ln_n(int64_t n) { return sqrt(2 * log(static_cast<double>(n))); }
 
 // keys per lane of the register-resident selection kernels for a row of n samples, 0 when it is too long
-static int reg_kpl(int64_t n) {
-    if (getenv("VW_NO_REG_SELECT") != nullptr) return 0;
+static int reg_kpl(const PlanOptions& opt, int64_t n) {
+    if (opt.no_reg_select) return 0;
     if (n <= 256) return 4;
     if (n <= 512) return 8;
     if (n <= 1024) return 16;
@@ -1069,9 +1173,9 @@ static int reg_kpl(int64_t n) {
     return 0;
 }
 
-static void launch_universal_threshold(const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
+static void launch_universal_threshold(const vw_ctx* ctx, const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
     const dim3 grid(static_cast<unsigned>(b));
-    switch (reg_kpl(n)) {
+    switch (reg_kpl(ctx->opt, n)) {
         case 4: hipLaunchKernelGGL(k_universal_threshold_reg<4>, grid, dim3(64), 0, s, a); return;
         case 8: hipLaunchKernelGGL(k_universal_threshold_reg<8>, grid, dim3(64), 0, s, a); return;
         case 16: hipLaunchKernelGGL(k_universal_threshold_reg<16>, grid, dim3(64), 0, s, a); return;
@@ -1094,7 +1198,7 @@ static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     a.lds_cap = 4096;
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
     if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-    launch_universal_threshold(a, b, n, lds, s);
+    launch_universal_threshold(ctx, a, b, n, lds, s);
     VW_HIP(ctx, hipGetLastError());
     return VW_OK;
 }
@@ -1142,7 +1246,7 @@ extern "C" int32_t vw_swt_universal_threshold_batch(vw_ctx* ctx, const double* c
     a.thr_out = t;
     a.lds_cap = 4096;
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
-    launch_universal_threshold(a, b, n, lds, ctx->stream);
+    launch_universal_threshold(ctx, a, b, n, lds, ctx->stream);
     VW_HIP(ctx, hipGetLastError());
     VW_HIP(ctx, hipMemcpyAsync(thresholds, t, static_cast<size_t>(b) * 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1175,6 +1279,12 @@ __global__ void __launch_bounds__(kThreads) k_threshold_rows(double* coeffs, int
         p[i] = apply_thr(p[i], thr[row * thr_row_stride + (i / n) * thr_level_stride], mode);
 }
 
+static size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+static int swt_denoise_run(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels, const double* h, int32_t lh,
+                           const double* g, int32_t lg, const double* hr, int32_t lhr, const double* gr, int32_t lgr,
+                           int32_t boundary, double threshold, double sqrt_2_ln_n, int32_t soft, double* y_dev,
+                           double* thresholds_out_dev, char* wsb, hipStream_t s);
+
 extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
                                             const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
                                             int32_t lhr, const double* gr, int32_t lgr, int32_t boundary,
@@ -1199,6 +1309,16 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
         if (rc != VW_OK) return rc;
         wsb = static_cast<char*>(ctx->denoise_ws.p);
     }
+    return swt_denoise_run(ctx, x_dev, b, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+                           thresholds_out_dev, wsb, s);
+}
+
+// forward -> per-row threshold -> thresholding inverse, all in the workspace `wsb` (coefficient block + thresholds)
+static int swt_denoise_run(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels, const double* h, int32_t lh,
+                           const double* g, int32_t lg, const double* hr, int32_t lhr, const double* gr, int32_t lgr,
+                           int32_t boundary, double threshold, double sqrt_2_ln_n, int32_t soft, double* y_dev,
+                           double* thresholds_out_dev, char* wsb, hipStream_t s) {
+    int rc;
     double* coeffs = reinterpret_cast<double*>(wsb);
     double* thr = reinterpret_cast<double*>(wsb + static_cast<size_t>(b) * (levels + 1) * n * 8);
 
@@ -1274,8 +1394,6 @@ extern "C" int32_t vw_swt_denoise_batch(vw_ctx* ctx, const double* x, int64_t b,
 // ---------------------------------------------------------------------------
 // WaveletDenoiser
 // ---------------------------------------------------------------------------
-
-static size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 extern "C" size_t vw_wavelet_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels) {
     if (b <= 0 || n <= 0 || levels < 1) return 0;
@@ -1364,7 +1482,7 @@ static int threshold_inverse_dev(vw_ctx* ctx, double* coeffs, int64_t b, int64_t
                                  const double* gr, int lgr, int boundary, uint32_t tflags, int soft, const double* thr,
                                  double* y_dev, hipStream_t s) {
     const bool single = (tflags & VW_FLAG_SINGLE_LEVEL) != 0;
-    const int mode = soft ? 1 : 2;
+    const int mode = soft ? 3 : 2;  // WaveletDenoiser.applyThreshold: the `abs <= thr ? 0.0 : ...` form
     bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
     if (!single) {
         for (int j = 1; j <= levels; ++j) {
@@ -1642,7 +1760,7 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
             const size_t lds = staged > 0 ? static_cast<size_t>((staged + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
             const dim3 grid(static_cast<unsigned>(b));
             if (do_level == do_update && !(do_level && noise_estimation == VW_NOISE_STD)) {  // MAD, or the threshold alone
-                const int kw = do_update ? reg_kpl(state->window) : 1, kn = want_thr ? reg_kpl(n) : 1;
+                const int kw = do_update ? reg_kpl(ctx->opt, state->window) : 1, kn = want_thr ? reg_kpl(ctx->opt, n) : 1;
                 if (kw != 0 && kn != 0) {
                     if (do_update) switch (kw) {
                         case 4: hipLaunchKernelGGL(k_stream_ring_mad_reg<4>, grid, dim3(64), 0, s, a); break;
@@ -1661,7 +1779,7 @@ extern "C" int32_t vw_streaming_denoise_batch_dev(vw_ctx* ctx, vw_stream_state* 
             }
             hipLaunchKernelGGL(k_stream_noise<kThreads>, dim3(static_cast<unsigned>(b)), dim3(kThreads), lds, s, a);
         };
-        if (noise_estimation == VW_NOISE_STD && getenv("VW_NO_STD_CHAINS") == nullptr) {
+        if (noise_estimation == VW_NOISE_STD && !ctx->opt.no_std_chains) {
             launch(1, 0, 0);
             hipLaunchKernelGGL(k_stream_std, dim3(static_cast<unsigned>((b + kChainRows - 1) / kChainRows)), dim3(64), 0, s, a);
             if (!plain) launch(0, 0, 1);
@@ -1811,22 +1929,40 @@ extern "C" int32_t vw_swt_sparsify_batch(vw_ctx* ctx, const double* coeffs, int6
     const int64_t total = offsets[bands];  // the caller's prefix sum ends with the number of entries
     rc = check_offsets(ctx, offsets, bands, n);
     if (rc != VW_OK) return rc;
-    const size_t obytes = round256(static_cast<size_t>(bands) * 8);
+    const size_t obytes = round256(static_cast<size_t>(bands + 1) * 8);
+    const size_t cbytes2 = round256(static_cast<size_t>(bands) * 8);
     const size_t ibytes = round256(static_cast<size_t>(total) * 4);
-    rc = ensure(ctx, ctx->stage_out, obytes + ibytes + static_cast<size_t>(total) * 8 + 256);
+    rc = ensure(ctx, ctx->stage_out, obytes + cbytes2 + ibytes + static_cast<size_t>(total) * 8 + 256);
     if (rc != VW_OK) return rc;
     char* base = static_cast<char*>(ctx->stage_out.p);
     int64_t* doff = reinterpret_cast<int64_t*>(base);
-    int32_t* didx = reinterpret_cast<int32_t*>(base + obytes);
-    double* dval = reinterpret_cast<double*>(base + obytes + ibytes);
-    VW_HIP(ctx, hipMemcpyAsync(doff, offsets, static_cast<size_t>(bands) * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = vw_swt_sparsify_batch_dev(ctx, dc, b, n, levels, threshold, nullptr, doff, didx, dval, ctx->stream);
+    int64_t* dfound = reinterpret_cast<int64_t*>(base + obytes);
+    int32_t* didx = reinterpret_cast<int32_t*>(base + obytes + cbytes2);
+    double* dval = reinterpret_cast<double*>(base + obytes + cbytes2 + ibytes);
+    VW_HIP(ctx, hipMemcpyAsync(doff, offsets, static_cast<size_t>(bands + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = vw_swt_sparsify_batch_dev(ctx, dc, b, n, levels, threshold, dfound, doff, didx, dval, ctx->stream);
     if (rc != VW_OK) return rc;
     if (total > 0) {
         VW_HIP(ctx, hipMemcpyAsync(indices, didx, static_cast<size_t>(total) * 4, hipMemcpyDeviceToHost, ctx->stream));
         VW_HIP(ctx, hipMemcpyAsync(values, dval, static_cast<size_t>(total) * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t* found = static_cast<int64_t*>(malloc(static_cast<size_t>(bands) * 8));
+    if (found == nullptr) return set_err(ctx, VW_E_NOMEM, "out of host memory");
+    hipError_t he = hipMemcpyAsync(found, dfound, static_cast<size_t>(bands) * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    int64_t bad_band = -1;
+    if (he == hipSuccess)
+        for (int64_t k = 0; k < bands && bad_band < 0; ++k)
+            if (found[k] != offsets[k + 1] - offsets[k]) bad_band = k;
+    const int64_t bad_found = bad_band >= 0 ? found[bad_band] : 0;
+    free(found);
+    if (he != hipSuccess) return set_err(ctx, VW_E_HIP, "sparsify copy back: %s", hipGetErrorString(he));
+    if (bad_band >= 0)
+        return set_err(ctx, VW_E_LENGTH_MISMATCH,
+                       "band %lld holds %lld entries above the threshold but offsets leave room for %lld: the fill pass must see the "
+                       "coefficients and threshold of the counting pass (surplus entries were dropped, nothing was written out of bounds)",
+                       static_cast<long long>(bad_band), static_cast<long long>(bad_found),
+                       static_cast<long long>(offsets[bad_band + 1] - offsets[bad_band]));
     return VW_OK;
 }
 

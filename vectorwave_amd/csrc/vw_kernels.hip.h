@@ -82,7 +82,7 @@ struct InvArgs {
     int32_t tiles_per_row, nchunks, ndry, hist_cap;
     int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     uint32_t band_mask;    // bit (j-1): use W_j, else zeros; bit 31: use rin, else zeros
-    int32_t thr_mode;      // 0 none, 1 soft, 2 hard: applied to W_j as it is loaded
+    int32_t thr_mode;      // 0 none, else a mode of apply_thr: applied to W_j as it is loaded
     const double* thr;     // threshold of row r, level j at thr[r*thr_row_stride + (j-1)*thr_level_stride] (thr_mode != 0)
     int64_t thr_row_stride, thr_level_stride;
     unsigned long long* first_bad;  // flat index into the coefficient block of the first NaN/Inf
@@ -148,20 +148,21 @@ __device__ __forceinline__ bool finite_f64(double v) {
     return (__double_as_longlong(v) & 0x7ff0000000000000LL) != 0x7ff0000000000000LL;
 }
 
-// MutableMultiLevelMODWTResult.applyThresholdToArray of the reference.
-// mode 1: soft  |c| > thr ? signum(c) * (|c| - thr) : 0.0
-// mode 2: hard  |c| <= thr ? 0.0 : c
+// The reference thresholds in two forms that differ only for NaN operands (a NaN threshold or coefficient):
+// mode 1: soft, MutableMultiLevelMODWTResult.applyThreshold (modwt/MutableMultiLevelMODWTResult.java:97-114):
+//         |c| > thr ? signum(c) * (|c| - thr) : 0.0            -- a NaN comparison zeroes the coefficient
+// mode 2: hard, every caller:  |c| <= thr ? 0.0 : c
+// mode 3: soft, WaveletDenoiser.applyThreshold / VectorOps.Denoising.softThreshold
+//         (denoising/WaveletDenoiser.java:554-559, internal/VectorOps.java:454-459):
+//         |c| <= thr ? 0.0 : signum(c) * (|c| - thr)           -- a NaN comparison propagates the NaN
 __device__ __forceinline__ double apply_thr(double c, double thr, int mode) {
     const double a = fabs(c);
-    if (mode == 1) {
-        if (a > thr) {
-            const double m = a - thr;
-            // signum(c) * m with signum in {+1, -1, +-0}: a > thr >= 0 excludes zero unless thr < 0
-            return c > 0.0 ? m : (c < 0.0 ? -m : c * m);
-        }
-        return 0.0;
-    }
-    return (a <= thr) ? 0.0 : c;
+    if (mode == 2) return (a <= thr) ? 0.0 : c;
+    const bool keep = (mode == 1) ? (a > thr) : !(a <= thr);
+    if (!keep) return 0.0;
+    const double m = a - thr;
+    // signum(c) * m with signum in {+1, -1, +-0, NaN}
+    return c > 0.0 ? m : (c < 0.0 ? -m : c * m);
 }
 
 // ---------------------------------------------------------------------------

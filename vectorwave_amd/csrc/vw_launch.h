@@ -25,7 +25,8 @@ struct SdryShape {
 constexpr SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
 
 
-hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+// unroll: filters of exactly 8 + 8 taps take the fully unrolled tap loop
+hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);

@@ -21,8 +21,8 @@ static hipError_t launch_fwd_stream_lt(const FwdArgs& a, bool vec2, bool fma, in
 }
 // filters of exactly 8 + 8 taps (db4, sym4, ...) on 16-byte-aligned rows take the fully unrolled tap loop
 template <int NT, int P, int MODE>
-static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (a.lh == 8 && a.lg == 8 && getenv("VW_NO_UNROLL") == nullptr)
+static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, bool unroll, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (a.lh == 8 && a.lg == 8 && unroll)
         return launch_fwd_stream_lt<NT, P, MODE, 8>(a, vec2, fma, nblocks, lds, stream);
     return launch_fwd_stream_lt<NT, P, MODE, 0>(a, vec2, fma, nblocks, lds, stream);
 }
@@ -32,11 +32,11 @@ static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, in
                                  : launch_fwd_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
 #define VW_FWD_STREAM_CASE(NT, P)                                                                            \
     if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == NT)                                                        \
-        return mode == kPeriodic ? launch_fwd_stream_pm<NT, P, kPeriodic>(a, vec2, fma, nblocks, lds, stream) \
-                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+        return mode == kPeriodic ? launch_fwd_stream_pm<NT, P, kPeriodic>(a, vec2, fma, unroll, nblocks, lds, stream) \
+                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, unroll, nblocks, lds, stream);
 
-hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
-                             hipStream_t stream) {
+hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks,
+                      hipStream_t stream) {
     const size_t lds = cfg.lds_bytes(false);
     VW_FWD_STREAM_CASE(256, 1)
     VW_FWD_STREAM_CASE(256, 2)
