@@ -112,10 +112,10 @@ def test_masks_long_context_plan(ctx, plan, chunks, mode):
 
 @pytest.mark.parametrize("mode", [P, Z])
 def test_masks_multi_group_plan(ctx, plan, mode):
-    """Long-context kernels off: coif3 J=7 needs more than one halo group, so the running reconstruction ping-pongs
-    through the context's plane and the mask has to reach every group."""
+    """Long-context kernels off: db20 J=8 (context 39 * 255 samples, beyond the largest halo shape) needs two halo
+    groups, so the running reconstruction ping-pongs through the context's plane and the mask has to reach both."""
     plan("no_sdry", 1)
-    _check_all_masks(ctx, "coif3", 2, 12288, 7, mode, "coif3 N=12288 J=7 multi-group mode=%d" % mode)
+    _check_all_masks(ctx, "db20", 2, 16384, 8, mode, "db20 N=16384 J=8 multi-group mode=%d" % mode)
 
 
 @pytest.mark.parametrize("mode", [BoundaryMode.PERIODIC, BoundaryMode.ZERO_PADDING])
