@@ -239,6 +239,26 @@ int32_t vw_swt_denoise_batch_dev(vw_ctx *ctx, const double *x_dev, int64_t b, in
                                  size_t workspace_bytes, void *stream);
 size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
 
+/* vw_swt_denoise_batch_dev for callers that cannot allocate device memory (no counterpart in the reference):
+ * code under HIP graph capture, tight serving loops over fixed-size blocks, harnesses that forbid hipMalloc.
+ * Same arguments, kernels and results (bit for bit) as vw_swt_denoise_batch_dev without its workspace
+ * parameters: the coefficient block, the per-row thresholds and the intermediate plane of multi-pass plans live
+ * in a static array of VW_NOALLOC_SCRATCH_BYTES bytes that is part of the library's device code -- one copy per
+ * GPU, held from library load until the process ends.  The call makes no hipMalloc/hipFree and no other
+ * allocating call.  Limit: vw_swt_denoise_workspace_bytes(b, n, levels) rounded up to 256 (plus b*n*8 for the
+ * rare multi-pass plans) must not exceed VW_NOALLOC_SCRATCH_BYTES, else VW_E_WORKSPACE and nothing is
+ * enqueued; the 8192 x 480, J = 4 streaming block needs 157,352,192 bytes.  Every call on one GPU uses that
+ * GPU's one array (whatever the context or stream) and leaves its last contents there: calls that overlap in
+ * time on one GPU race and must be ordered by the caller (one stream, or events); nothing in the array needs
+ * clearing between calls, every byte a call reads was written by that call. */
+#define VW_NOALLOC_SCRATCH_BYTES ((size_t)160 << 20)
+int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
+                                         int32_t levels, const double *h, int32_t lh, const double *g,
+                                         int32_t lg, const double *hr, int32_t lhr, const double *gr,
+                                         int32_t lgr, int32_t boundary, double threshold,
+                                         double sqrt_2_ln_n, int32_t soft, double *y_dev,
+                                         double *thresholds_out_dev, void *stream);
+
 /* ---- WaveletDenoiser --------------------------------------------------------- */
 
 /* Threshold selection methods of denoising/WaveletDenoiser.java:588-617. */

@@ -78,6 +78,9 @@ SIGNATURES = {
                                              _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                              C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "vw_swt_denoise_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "vw_swt_denoise_batch_noalloc_dev": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp,
+                                                     C.c_int32, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double,
+                                                     C.c_double, C.c_int32, _vp, _vp, _vp]),
     "vw_wavelet_denoise_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
                                              _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
                                              C.c_double, C.c_double, _vp, _vp]),

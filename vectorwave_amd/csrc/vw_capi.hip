@@ -61,6 +61,7 @@ struct vw_ctx {
     DevBuf denoise_ws;  // coefficient block for vw_swt_denoise_batch(_dev) when the caller passes none
     DevBuf cell;        // 8-byte first_bad cell for host-pointer entry points
     DevBuf ws_borrow;   // set (under mu) by an entry point that may not allocate: stands in for `ws`, never freed
+    void* scratch = nullptr;  // this device's copy of the static scratch array (looked up in vw_init)
     int lds_limit = 65536;
     PlanOptions opt;
 };
@@ -109,6 +110,36 @@ static int ensure_ws(vw_ctx* ctx, size_t bytes, double** out) {
     const int rc = ensure(ctx, ctx->ws, bytes);
     *out = static_cast<double*>(ctx->ws.p);
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// static device scratch of the allocation-free entry point
+// ---------------------------------------------------------------------------
+//
+// One array per GPU, part of this code object, held from the moment the library is loaded on that GPU until
+// the process ends.  `vw_scratch` is only a symbol on the host side: its device address differs per GPU and is
+// looked up once per device in vw_init (that device current) and kept in g_scratch_ptr[]; every use below goes
+// through that pointer.
+static constexpr size_t kScratchBytes = VW_NOALLOC_SCRATCH_BYTES;
+static constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char vw_scratch[kScratchBytes];
+static void* g_scratch_ptr[kMaxDevices] = {nullptr};
+static std::mutex g_scratch_mu;
+
+static int scratch_lookup(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return VW_E_NO_DEVICE;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device] == nullptr) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(vw_scratch));  // the current device's copy
+        if (e != hipSuccess || p == nullptr) {
+            (void)hipGetLastError();
+            return VW_E_HIP;
+        }
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return VW_OK;
 }
 
 static bool parse_pair(int64_t v, int* p, int* h) {
@@ -208,6 +239,13 @@ extern "C" int32_t vw_init(int32_t device, vw_ctx** out_ctx) {
         snprintf(ctx->info, sizeof(ctx->info), "HIP device %d", device);
     }
     strcpy(ctx->err, "no error");
+    void* scratch = nullptr;
+    if (scratch_lookup(device, &scratch) != VW_OK) {  // `device` is current here
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return VW_E_HIP;
+    }
+    ctx->scratch = scratch;
 #ifdef VW_TUNING
     tuning_env(ctx);
     strncat(ctx->info, " [TUNING BUILD: ablation hooks enabled]", sizeof(ctx->info) - strlen(ctx->info) - 1);
@@ -1311,6 +1349,38 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
     }
     return swt_denoise_run(ctx, x_dev, b, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
                            thresholds_out_dev, wsb, s);
+}
+
+// Entry point that allocates nothing (no counterpart in the reference).  Same kernels and results as
+// vw_swt_denoise_batch_dev; the coefficient block, the thresholds and -- for plans of more than one pass -- the
+// intermediate plane live in the static per-GPU scratch array instead of context-owned or caller-owned memory.
+extern "C" int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels,
+                                                    const double* h, int32_t lh, const double* g, int32_t lg, const double* hr,
+                                                    int32_t lhr, const double* gr, int32_t lgr, int32_t boundary,
+                                                    double threshold, double sqrt_2_ln_n, int32_t soft, double* y_dev,
+                                                    double* thresholds_out_dev, void* stream) {
+    int rc = forward_checks(ctx, x_dev, b, n, levels, h, lh, g, lg, boundary, 0, y_dev);
+    if (rc != VW_OK) return rc;
+    rc = inverse_checks(ctx, x_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, y_dev);
+    if (rc != VW_OK) return rc;
+    if (b == 0) return VW_OK;
+    const size_t need = round256(vw_swt_denoise_workspace_bytes(b, n, levels));
+    if (need > kScratchBytes)
+        return set_err(ctx, VW_E_WORKSPACE,
+                       "batch of %lld x %lld samples at %d levels needs %zu bytes of scratch; the allocation-free entry point "
+                       "holds %zu (VW_NOALLOC_SCRATCH_BYTES): split the batch or use vw_swt_denoise_batch_dev",
+                       static_cast<long long>(b), static_cast<long long>(n), levels, need, kScratchBytes);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    VW_HIP(ctx, hipSetDevice(ctx->device));
+    char* base = static_cast<char*>(ctx->scratch);  // device address of this GPU's array, never the symbol itself
+    // what the coefficient block leaves of the array serves multi-pass plans as their intermediate plane
+    ctx->ws_borrow.p = base + need;
+    ctx->ws_borrow.bytes = kScratchBytes - need;
+    rc = swt_denoise_run(ctx, x_dev, b, n, levels, h, lh, g, lg, hr, lhr, gr, lgr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+                         thresholds_out_dev, base, static_cast<hipStream_t>(stream));
+    ctx->ws_borrow.p = nullptr;
+    ctx->ws_borrow.bytes = 0;
+    return rc;
 }
 
 // forward -> per-row threshold -> thresholding inverse, all in the workspace `wsb` (coefficient block + thresholds)
