@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the secondary run in the other arithmetic mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--plan", action="append", default=[], metavar="NAME=VALUE",
+                    help="vw_set_plan_option before the run (A/B of equivalent plans, e.g. --plan no_blk=1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: ranks rendezvous over gloo, shard the rows, time a stub and print the line "
                          "(exercises the launcher, the sharding and the timing reduction on a CPU box)")
@@ -231,6 +233,9 @@ def main():
 
     ctx = N.Context(local_rank)
     lib = ctx.lib
+    for opt in args.plan:
+        name, _, val = opt.partition("=")
+        ctx.set_plan_option(name, int(val))
     dp = C.POINTER(C.c_double)
     h = np.ascontiguousarray(w.dec_lo, dtype=np.float64)
     g = np.ascontiguousarray(w.dec_hi, dtype=np.float64)

@@ -292,3 +292,54 @@ def test_status_codes(ctx):
     assert st == 0
     st, _, _ = gpu_forward(ctx, np.zeros((2, 0)), "haar", 1, P, N.VW_FLAG_SINGLE_LEVEL)
     assert st == N.VW_E_EMPTY
+
+
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("variant", ["ring", "blk", "fused"])
+@pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("db4", 2560, 5, 2), ("db4", 6002, 6, 2), ("haar", 8192, 8, 2),
+                                      ("haar", 20480, 7, 1), ("db2", 12290, 7, 2), ("sym4", 4096, 4, 3), ("db4", 2048, 1, 2),
+                                      ("db4", 30000, 2, 1), ("bior1.3", 9000, 6, 2)])
+def test_inverse_tile_kernel_families_bit_exact(ctx, plan, wn, n, j, b, variant, mode):
+    """The three inverse tile kernels behind one plan -- LDS-DMA ring (default on 16-byte-aligned rows of 2560+ samples),
+    register-blocked with register landing, and the unblocked k_inv_fused -- must each reproduce the oracle: plain
+    inverse, inverse with the finite check, thresholding inverse (denoise) and band-masked inverse, on interior
+    tiles, on the last tile of a row (wrap / zeros) and on rows that are not a whole number of tiles."""
+    import ctypes as C
+    if variant == "blk":
+        plan("no_ring", 1)
+    elif variant == "fused":
+        plan("no_blk", 1)
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=n + j)
+    st, coeffs = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    want = o.reconstruct_batch(coeffs, w, mode)
+    st, got, _ = gpu_inverse(ctx, coeffs, wn, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "%s inverse %s N=%d J=%d" % (variant, wn, n, j))
+    st, got, bad = gpu_inverse(ctx, coeffs, wn, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == 0 and bad == -1
+    assert_bits_equal(got, want, "%s checked inverse" % variant)
+    cb = coeffs.copy()
+    bad_at = ((b - 1) * (j + 1) + j // 2) * n + (n * 3) // 4
+    cb.reshape(-1)[bad_at] = np.inf
+    st, _, bad = gpu_inverse(ctx, cb, wn, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == bad_at
+    st, wantd = o.swt_denoise_batch(x, w, j, -1.0, True, mode)
+    assert st == 0
+    st, gotd, _ = gpu_denoise(ctx, x, wn, j, mode, -1.0, True)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(gotd, wantd, "%s denoise" % variant)
+    # a band mask: keep the approximation and every second detail band
+    mask = (1 << j) | sum(1 << k for k in range(0, j, 2))
+    z = coeffs.copy()
+    for k in range(j):
+        if not (mask >> k) & 1:
+            z[:, k, :] = 0.0
+    hr, gr = np.ascontiguousarray(w.rec_lo, dtype=np.float64), np.ascontiguousarray(w.rec_hi, dtype=np.float64)
+    out = np.full((b, n), np.nan)
+    dp = C.POINTER(C.c_double)
+    st = ctx.lib.vw_modwt_inverse_bands_batch(ctx.handle, C.c_void_p(coeffs.ctypes.data), b, n, j, hr.ctypes.data_as(dp), hr.size,
+                                              gr.ctypes.data_as(dp), gr.size, mode, mask, C.c_void_p(out.ctypes.data))
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(out, o.reconstruct_batch(z, w, mode), "%s masked inverse" % variant)

@@ -44,6 +44,8 @@ struct PlanOptions {
     int no_reg_select = 0;               // 1: LDS/global selection kernels also for short rows
     int no_std_chains = 0;               // 1: plain reduction kernel for the streaming STD
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
+    int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
+    int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
 #ifdef VW_TUNING
     char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
 #endif
@@ -179,6 +181,10 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_std_chains = value != 0;
     } else if (strcmp(name, "no_row_denoise") == 0) {
         o.no_row_denoise = value != 0;
+    } else if (strcmp(name, "no_blk") == 0) {
+        o.no_blk = value != 0;
+    } else if (strcmp(name, "no_ring") == 0) {
+        o.no_ring = value != 0;
     } else {
         return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
     }
@@ -190,7 +196,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_std_chains", "no_row_denoise"};
+                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -1003,11 +1009,17 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (strstr(ctx->opt.ablate, "nocompute")) a.lh = 0;
             if (strstr(ctx->opt.ablate, "nohalo"))
                 for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
+            if (strstr(ctx->opt.ablate, "ringnomath")) a.ablate |= 1;
+            if (strstr(ctx->opt.ablate, "ringnoload")) a.ablate |= 2;
 #endif
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t er = launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1);
+            const bool ring = blk && vec2 && n >= 2560 && !ctx->opt.no_ring && ctx->lds_limit >= 81920;
+            hipError_t er = ring  ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
+                            : blk ? launch_inv_blk(a, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
+                                  : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
             if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));
         } else {
             if (first && first_bad_cell != nullptr)

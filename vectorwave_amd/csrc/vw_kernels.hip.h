@@ -88,8 +88,17 @@ struct InvArgs {
     unsigned long long* first_bad;  // flat index into the coefficient block of the first NaN/Inf
     int32_t check_rin;     // rin is the a_J band of the block (top group): include it in the check
     int32_t nt_store;      // results are stored with the streaming hint (launches far larger than the caches)
+    int32_t ablate;        // tuning build only (bit 0: no arithmetic, bit 1: no band loads); always 0 in the product
     Taps taps;
 };
+
+// Parts of a kernel that the tuning build (-DVW_TUNING, tools/ only) can switch off to time what is left.  In the
+// product build the test is a compile-time false and the code below it is the only code.
+#ifdef VW_TUNING
+#define VW_ABLATED(args, bit) (((args).ablate >> (bit)) & 1)
+#else
+#define VW_ABLATED(args, bit) false
+#endif
 
 // ---------------------------------------------------------------------------
 // helpers
@@ -1006,6 +1015,569 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// register-blocked inverse: the tile kernel with sliding operand windows
+// ---------------------------------------------------------------------------
+//
+// k_inv_fused reads both operands of every tap of every output pair from LDS: 2*L 16-byte reads per
+// pair and level.  Outputs that lie a multiple of the level's stride apart share operands -- output
+// t + k*s at tap l reads position t + (k + l)*s -- so here a lane owns, at a level with stride s = 2*sp
+// samples, the four pairs P0 + k*sp (k = 0..3, pair index = position / 2) and walks the window
+// c = k + l = 0..L+2 once: L + 3 reads per operand for four pairs instead of 4*L, each operand used by
+// up to four accumulators straight from registers.  Every accumulator still receives its taps in
+// ascending order, so the bits do not change.  The ownership differs from level to level (it follows
+// the stride); that costs nothing because R_j travels through LDS between levels anyway.
+//
+// LDS layout.  Ownership in blocks of 4*sp pairs makes the 16 lanes that one LDS pass serves hit
+// addresses that are multiples of 64*sp bytes apart, i.e. the same banks.  The buffers that level j
+// reads are therefore stored swizzled for that level: pair index p sits in 16-byte slot
+// p ^ (((p >> 4) & 3) << S) for sp = 2^S <= 4, p ^ (((p >> 5) & 1) << 3) for sp = 8, p itself for
+// sp >= 16 and for level 1 -- a permutation inside each aligned block of 16 slots that spreads the 16
+// lanes of a pass over all 16 slot residues.  Writers (the staging of W_j, the write-back of R_{j-1})
+// apply the swizzle of the level that will read.
+//
+// Level 1 (stride one sample) keeps the chunk ownership (pair tid + 256*k) and reads its window as
+// L/2 + 1 aligned 16-byte pairs per operand.  The halo pair of a lane (pair 1024 + tid, needed only
+// while lower levels remain) is computed tap by tap as in k_inv_fused, switched on per wave.
+// Shape: 256 lanes, 2048-sample tile + 512-sample halo, both filters of exactly LT taps, levels <= 8.
+
+template <int S>
+__device__ __forceinline__ int blk_slot(int pair) {  // S = log2(sp) of the reading level; S < 0: level 1
+    if (S < 0 || S >= 4) return pair;
+    if (S == 3) return pair ^ (((pair >> 5) & 1) << 3);
+    return pair ^ (((pair >> 4) & 3) << S);
+}
+__device__ __forceinline__ int blk_slot_rt(int pair, int S) {
+    if (S < 0 || S >= 4) return pair;
+    const int sh = (S == 3) ? 5 : 4, mask = (S == 3) ? 1 : 3;
+    return pair ^ (((pair >> sh) & mask) << S);
+}
+
+constexpr int kBlkPairs = 5 * kThreads;        // pairs per buffer: 4 tile chunks + 1 halo chunk
+constexpr int kBlkWOff = kBlkPairs * 16;       // byte offset of the W buffer behind the R buffer
+
+template <bool FMA>
+__device__ __forceinline__ double inv_pair_mac(double acc, double flo, double r, double fhi, double w) {
+    // sum += lo[l]*a[idx] + hi[l]*d[idx]
+    return FMA ? __builtin_fma(flo, r, __builtin_fma(fhi, w, acc)) : acc + (flo * r + fhi * w);
+}
+
+// main round of a level with stride 2^S pairs (S compile-time: swizzled addresses fold to shifts and xors;
+// S >= 4: SRT carries the run-time log2 and no swizzle applies)
+// PRELOAD: the whole operand window is requested before the first multiply (a scheduling fence keeps the
+// compiler from sinking the reads next to their uses), so that one wave covers its own LDS latency; costs
+// 8 * (LT + 3) registers and is meant for the two-waves-per-SIMD ring kernel.
+template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+__device__ __forceinline__ void inv_blk_main(const char* lds, int tid, int SRT, const double (&tl)[LT], const double (&th)[LT],
+                                             double (&acc)[5][2], int& P0out) {
+    const int sl = (S >= 4) ? SRT : S;
+    const int sp = 1 << sl;
+    const int P0 = ((tid >> sl) << (sl + 2)) + (tid & (sp - 1));
+    P0out = P0;
+    if (PRELOAD) {
+        double2 r[LT + 3], w[LT + 3];
+#pragma unroll
+        for (int c = 0; c < LT + 3; ++c) {
+            const int adr = blk_slot<S>(P0 + c * sp) << 4;
+            r[c] = *reinterpret_cast<const double2*>(lds + adr);
+            w[c] = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < LT + 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int l = c - k;
+                if (l >= 0 && l < LT) {
+                    acc[k][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][0], tl[l], r[c].x, th[l], w[c].x);
+                    acc[k][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][1], tl[l], r[c].y, th[l], w[c].y);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < LT + 3; ++c) {
+        const int adr = blk_slot<S>(P0 + c * sp) << 4;
+        const double2 r = *reinterpret_cast<const double2*>(lds + adr);
+        const double2 w = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = c - k;
+            if (l >= 0 && l < LT) {
+                acc[k][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][0], tl[l], r.x, th[l], w.x);
+                acc[k][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][1], tl[l], r.y, th[l], w.y);
+            }
+        }
+    }
+}
+
+// halo pair of a lane at a blocked level: one pair, tap by tap (wave-uniform switch outside)
+template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+__device__ __forceinline__ void inv_blk_halo(const char* lds, int ph, int SRT, const double (&tl)[LT], const double (&th)[LT],
+                                             double (&acc)[5][2]) {
+    const int sl = (S >= 4) ? SRT : S;
+    const int sp = 1 << sl;
+    if (PRELOAD) {
+        double2 r[LT], w[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            const int adr = blk_slot<S>(ph + l * sp) << 4;
+            r[l] = *reinterpret_cast<const double2*>(lds + adr);
+            w[l] = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            acc[4][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][0], tl[l], r[l].x, th[l], w[l].x);
+            acc[4][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][1], tl[l], r[l].y, th[l], w[l].y);
+        }
+        return;
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        const int adr = blk_slot<S>(ph + l * sp) << 4;
+        const double2 r = *reinterpret_cast<const double2*>(lds + adr);
+        const double2 w = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+        acc[4][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][0], tl[l], r.x, th[l], w.x);
+        acc[4][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][1], tl[l], r.y, th[l], w.y);
+    }
+}
+
+// level 1: chunk ownership, window of LT/2 + 1 aligned pairs per operand
+template <int LT, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+__device__ __forceinline__ void inv_blk_level1(const char* lds, int tid, const double (&tl)[LT], const double (&th)[LT],
+                                               double (&acc)[5][2]) {
+    constexpr int NW = LT / 2 + 1;
+    if (PRELOAD) {
+        // two chunks' windows at a time
+#pragma unroll
+        for (int k0 = 0; k0 < 4; k0 += 2) {
+            double2 rr[2][NW], ww[2][NW];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    const int adr = ((k0 + kk) * kThreads + tid + q) << 4;
+                    rr[kk][q] = *reinterpret_cast<const double2*>(lds + adr);
+                    ww[kk][q] = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    const double r0 = (l & 1) ? rr[kk][l / 2].y : rr[kk][l / 2].x;
+                    const double r1 = (l & 1) ? rr[kk][l / 2 + 1].x : rr[kk][l / 2].y;
+                    const double w0 = (l & 1) ? ww[kk][l / 2].y : ww[kk][l / 2].x;
+                    const double w1 = (l & 1) ? ww[kk][l / 2 + 1].x : ww[kk][l / 2].y;
+                    acc[k0 + kk][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k0 + kk][0], tl[l], r0, th[l], w0);
+                    acc[k0 + kk][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k0 + kk][1], tl[l], r1, th[l], w1);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double r[2 * NW], w[2 * NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int adr = (k * kThreads + tid + q) << 4;
+            const double2 rr = *reinterpret_cast<const double2*>(lds + adr);
+            const double2 ww = *reinterpret_cast<const double2*>(lds + WOFF + adr);
+            r[2 * q] = rr.x;
+            r[2 * q + 1] = rr.y;
+            w[2 * q] = ww.x;
+            w[2 * q + 1] = ww.y;
+        }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            acc[k][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][0], tl[l], r[l], th[l], w[l]);
+            acc[k][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[k][1], tl[l], r[l + 1], th[l], w[l + 1]);
+        }
+    }
+}
+
+template <int LT, int MODE, bool VEC2, bool FMA>
+__global__ void __launch_bounds__(kThreads, 4) k_inv_blk(const InvArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int PPT = 4, NP = 5;
+    constexpr int T = PPT * kChunk;
+    char* lds = reinterpret_cast<char*>(vw_smem);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int tile = static_cast<int>(id - row * a.ntiles);
+    const int64_t t0 = static_cast<int64_t>(tile) * T;
+    const int64_t n = a.n;
+    const double* __restrict__ wbase = a.win + row * a.w_row_stride;
+
+    double tl[LT], th[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) {
+        tl[i] = a.taps.lo[i];
+        th[i] = a.taps.hi[i];
+    }
+
+    double2 pre[NP];
+    // R_{lev1}, staged in the layout of the level that reads it.  The swizzle only looks at bits 4..5 of the pair
+    // index, which the chunk term 256*c does not touch: one swizzled base per lane and level serves all chunks.
+    inv_fetch<NP, MODE, VEC2>(a.rin + row * a.rin_stride, (a.band_mask >> 31) & 1u, t0, n, tid, a.pend[a.lev1], pre);
+    if (a.first_bad != nullptr && a.check_rin) {
+        const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
+#pragma unroll
+        for (int c = 0; c < PPT; ++c) {
+            const int64_t t = t0 + c * kChunk + 2 * tid;
+            if (t < n && !finite_f64(pre[c].x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+            if (t + 1 < n && !finite_f64(pre[c].y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+        }
+    }
+    {
+        const int base = blk_slot_rt(tid, a.lev1 - 2) << 4;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) *reinterpret_cast<double2*>(lds + base + c * (kThreads * 16)) = pre[c];
+    }
+    inv_fetch<NP, MODE, VEC2>(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, (a.band_mask >> (a.lev1 - 1)) & 1u, t0, n,
+                              tid, a.pend[a.lev1], pre);
+
+    for (int j = a.lev1; j >= a.lev0; --j) {
+        const int S = j - 2;
+        const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+        // publish W_j (thresholded on the way in when denoising) in this level's layout
+        {
+            const int base = (blk_slot_rt(tid, S) << 4) + kBlkWOff;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                double2 w = pre[c];
+                if (a.thr_mode != 0) {
+                    w.x = apply_thr(w.x, thr, a.thr_mode);
+                    w.y = apply_thr(w.y, thr, a.thr_mode);
+                }
+                if (a.first_bad != nullptr && c < PPT) {
+                    const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+                    const int64_t t = t0 + c * kChunk + 2 * tid;
+                    if (t < n && !finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                    if (t + 1 < n && !finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                }
+                *reinterpret_cast<double2*>(lds + base + c * (kThreads * 16)) = w;
+            }
+        }
+        lds_barrier();  // R_j and W_j visible
+        if (j > a.lev0)
+            inv_fetch<NP, MODE, VEC2>(wbase + static_cast<int64_t>(j - 2) * a.w_band_stride, (a.band_mask >> (j - 2)) & 1u, t0, n, tid,
+                                      a.pend[j - 1], pre);
+
+        const int pe = (j > a.lev0) ? a.pend[j - 1] : T;  // the last level only needs the tile
+        const bool hact = (T + 128 * wave) < pe;          // this wave owns halo pairs that lower levels need
+        const int ph_own = kThreads * PPT + tid;          // the lane's halo pair
+        const bool hwr = 2 * ph_own < pe;
+        const int ph = hwr ? ph_own : (pe >> 1) - 1;      // lanes right of the needed zone recompute its last pair
+        double acc[NP][2];
+        int P0 = 0;
+        acc[4][0] = acc[4][1] = 0.0;
+        switch (j) {
+            case 1:
+                inv_blk_level1<LT, FMA>(lds, tid, tl, th, acc);
+                break;
+            case 2:
+                inv_blk_main<LT, 0, FMA>(lds, tid, 0, tl, th, acc, P0);
+                if (hact) inv_blk_halo<LT, 0, FMA>(lds, ph, 0, tl, th, acc);
+                break;
+            case 3:
+                inv_blk_main<LT, 1, FMA>(lds, tid, 1, tl, th, acc, P0);
+                if (hact) inv_blk_halo<LT, 1, FMA>(lds, ph, 1, tl, th, acc);
+                break;
+            case 4:
+                inv_blk_main<LT, 2, FMA>(lds, tid, 2, tl, th, acc, P0);
+                if (hact) inv_blk_halo<LT, 2, FMA>(lds, ph, 2, tl, th, acc);
+                break;
+            case 5:
+                inv_blk_main<LT, 3, FMA>(lds, tid, 3, tl, th, acc, P0);
+                if (hact) inv_blk_halo<LT, 3, FMA>(lds, ph, 3, tl, th, acc);
+                break;
+            default:
+                inv_blk_main<LT, 4, FMA>(lds, tid, S, tl, th, acc, P0);
+                if (hact) inv_blk_halo<LT, 4, FMA>(lds, ph, S, tl, th, acc);
+                break;
+        }
+        // pair index of accumulator k in this level's ownership
+        const int sp = (j >= 2) ? (1 << S) : 0;
+
+        if (j == a.lev0) {
+            double* __restrict__ orow = a.rout + row * a.rout_stride;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int pair = (j == 1) ? k * kThreads + tid : P0 + k * sp;
+                const int64_t t = t0 + 2 * pair;
+                if (VEC2) {
+                    if (t < a.n_store) gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
+                } else {
+                    if (t < a.n_store) orow[t] = acc[k][0];
+                    if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
+                }
+            }
+        } else {
+            lds_barrier();  // every lane has finished reading R_j / W_j
+            // j > lev0 >= 1, so this is a blocked level; R_{j-1} goes into the layout of level j-1
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (k < PPT || hwr) {
+                    const int pair = (k < PPT) ? P0 + k * sp : ph_own;
+                    double2 v = make_double2(acc[k][0], acc[k][1]);
+                    if (MODE == kZeroPad) {
+                        // samples right of the signal are zero at every level
+                        const int64_t t = t0 + 2 * pair;
+                        if (t >= n) v.x = 0.0;
+                        if (t + 1 >= n) v.y = 0.0;
+                    }
+                    *reinterpret_cast<double2*>(lds + (blk_slot_rt(pair, S - 1) << 4)) = v;
+                }
+            }
+            // the barrier at the top of the next iteration publishes R_{j-1}
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_inv_ring: the register-blocked inverse fed by LDS-DMA, two detail bands ahead
+// ---------------------------------------------------------------------------
+//
+// The inverse reads seven planes per tile and every level depends on its band having arrived.  With the band
+// of the next level landing in registers (k_inv_fused, k_inv_blk) a workgroup has at most one band in flight
+// and waits out a full memory latency per level.  Here the bands go from HBM straight into LDS
+// (global_load_lds_dwordx4: no registers, no ds_write pass) into a ring of three band buffers, issued two
+// levels ahead: W_{j-2} is requested before level j starts, so two bands per workgroup are always in flight.
+// LDS: R + 3 band buffers of 20 KiB = 80 KiB, two workgroups per CU.
+//
+// An LDS-DMA instruction writes 64 consecutive 16-byte slots (wave-uniform base + lane * 16); the SOURCE
+// address is per lane.  The swizzled layouts of the blocked levels are therefore produced on the source side:
+// the lane that fills slot s fetches the pair whose swizzled position is s (the swizzle is an involution inside
+// aligned blocks of 16 slots).  Wave w fills the 1 KiB blocks w, w+4, ... of a band: always five instructions
+// per band and wave, so the number of younger requests at each wait is a constant (vmcnt counts in order):
+// before level j everything but the two youngest bands must have landed.  Slots right of the zone a level
+// needs are filled from a clamped address (valid memory, values never used).  Bands travel by slot j % 3.
+//
+// PLAIN = false adds a pass over the freshly landed slots of the wave (threshold-on-load for the denoisers,
+// band mask, finite check) and makes every wait a full drain; the plain form runs that pass only on the
+// ZERO_PADDING tiles that reach beyond their row (zeros right of the signal).
+// Needs 16-byte-aligned rows with even n >= 2560 (one wrap at most inside a tile's halo).
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// the same with a wave-uniform 64-bit base and a 32-bit byte offset per lane
+__device__ __forceinline__ void glds16_so(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+constexpr int kRingBand = kBlkPairs * 16;  // bytes per band buffer
+
+// One band (R or W_j of this tile) into the buffer at byte offset `dst`, in the layout of the level with log2
+// stride S.  Wave w fills the 1 KiB blocks w, w+4, ..., w+16: block index and chunk differ by multiples of 256
+// slots, which the swizzle (bits 4..5 of the slot index) does not see, so the five source addresses of a lane are
+// one swizzled offset plus multiples of 4096 bytes.  Only the halo chunk can lie right of the needed zone (clamped)
+// and only the last tile of a row reaches beyond the row (`edge`: wrapped or clamped lane by lane).
+template <int MODE>
+__device__ __forceinline__ void ring_issue(const double* __restrict__ src, unsigned lds_base, int dst, int S, int pl /*pairs needed*/,
+                                           int64_t t0, int64_t n, int wave, int lane, bool edge) {
+    const int pair0 = blk_slot_rt(64 * wave + lane, S);
+    const unsigned ldst = lds_base + dst + 1024 * wave;
+    if (!edge) {
+        const double* tsrc = src + t0;  // wave-uniform
+        const unsigned off0 = static_cast<unsigned>(pair0) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_so(tsrc, off0 + 4096u * i, ldst + 4096u * i);
+        const int p4 = pair0 + 4 * kThreads;
+        glds16_so(tsrc, static_cast<unsigned>(p4 < pl ? p4 : pl - 1) << 4, ldst + 4096u * 4);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int pair = pair0 + i * kThreads;
+        pair = pair < pl ? pair : pl - 1;
+        int64_t t = t0 + 2 * pair;
+        if (t >= n) t = (MODE == kPeriodic) ? t - n : n - 2;
+        glds16(src + t, ldst + 4096u * i);
+    }
+}
+
+// write-back of a blocked level's accumulators as R_{j-1}, in the layout of the level (log2 stride SR) that reads it
+template <int SR, int MODE>
+__device__ __forceinline__ void ring_writeback(char* lds, const double (&acc)[5][2], int P0, int sp, int ph_own, bool hwr, int64_t t0,
+                                               int64_t n) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (k < 4 || hwr) {
+            const int pair = (k < 4) ? P0 + k * sp : ph_own;
+            double2 v = make_double2(acc[k][0], acc[k][1]);
+            if (MODE == kZeroPad) {
+                // samples right of the signal are zero at every level
+                const int64_t t = t0 + 2 * pair;
+                if (t >= n) v.x = 0.0;
+                if (t + 1 >= n) v.y = 0.0;
+            }
+            *reinterpret_cast<double2*>(lds + (blk_slot<SR>(pair) << 4)) = v;
+        }
+    }
+}
+
+template <int LT, int MODE, bool FMA, bool PLAIN>
+__global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int PPT = 4, NP = 5;
+    constexpr int T = PPT * kChunk;
+    char* lds = reinterpret_cast<char*>(vw_smem);
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));  // LDS byte address of the R buffer
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int tile = static_cast<int>(id - row * a.ntiles);
+    const int64_t t0 = static_cast<int64_t>(tile) * T;
+    const int64_t n = a.n;
+    const double* __restrict__ wbase = a.win + row * a.w_row_stride;
+
+    double tl[LT], th[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) {
+        tl[i] = a.taps.lo[i];
+        th[i] = a.taps.hi[i];
+    }
+
+    // the tile (with its halo) reaches beyond its row: the loads wrap or clamp lane by lane, and a ZERO_PADDING tile
+    // needs zeros there even in the plain form
+    const bool redge = t0 + 2 * kBlkPairs > n;
+    const bool edge = (MODE == kZeroPad) && redge;
+
+    // prologue: R_{lev1}, W_{lev1}, W_{lev1-1}
+    if (!VW_ABLATED(a, 1)) ring_issue<MODE>(a.rin + row * a.rin_stride, lds_base, 0, a.lev1 - 2, a.pend[a.lev1] >> 1, t0, n, wave, lane, redge);
+    if (!VW_ABLATED(a, 1)) ring_issue<MODE>(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, lds_base, (1 + a.lev1 % 3) * kRingBand, a.lev1 - 2,
+                     a.pend[a.lev1] >> 1, t0, n, wave, lane, redge);
+    if (a.lev1 - 1 >= a.lev0 && !VW_ABLATED(a, 1))
+        ring_issue<MODE>(wbase + static_cast<int64_t>(a.lev1 - 2) * a.w_band_stride, lds_base, (1 + (a.lev1 - 1) % 3) * kRingBand,
+                         a.lev1 - 3, a.pend[a.lev1 - 1] >> 1, t0, n, wave, lane, redge);
+
+    for (int j = a.lev1; j >= a.lev0; --j) {
+        const int S = j - 2;
+        // two levels ahead; its slot was last read at level j+1, whose readers all passed that level's second barrier
+        if (j - 2 >= a.lev0 && !VW_ABLATED(a, 1))
+            ring_issue<MODE>(wbase + static_cast<int64_t>(j - 3) * a.w_band_stride, lds_base, (1 + (j - 2) % 3) * kRingBand, j - 4,
+                             a.pend[j - 2] >> 1, t0, n, wave, lane, redge);
+        // everything older than the two youngest bands has landed: R (first pass) and W_j
+        if (!PLAIN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (j - 2 >= a.lev0) {
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (j - 1 >= a.lev0) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!PLAIN || edge) {
+            // pass over the slots this wave has filled: W_j (and R on the first level)
+            const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+            const bool use_w = (a.band_mask >> (j - 1)) & 1u;
+            const bool use_r = (a.band_mask >> 31) & 1u;
+            const int wofs = (1 + j % 3) * kRingBand;
+            const int pl = a.pend[j] >> 1;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int slot = 64 * (wave + 4 * i) + lane;
+                const int pair = blk_slot_rt(slot, S);
+                const int64_t t = t0 + 2 * pair;
+                const bool inrow = (MODE == kPeriodic) || (t < n);
+                double2* pw = reinterpret_cast<double2*>(lds + wofs + 16 * slot);
+                double2 w = *pw;
+                if (!use_w || !inrow || pair >= pl) w = make_double2(0.0, 0.0);
+                if (a.thr_mode != 0) {
+                    w.x = apply_thr(w.x, thr, a.thr_mode);
+                    w.y = apply_thr(w.y, thr, a.thr_mode);
+                }
+                if (a.first_bad != nullptr && pair < kThreads * PPT && t < n) {
+                    const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+                    if (!finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                    if (!finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                }
+                *pw = w;
+                if (j == a.lev1) {
+                    double2* pr = reinterpret_cast<double2*>(lds + 16 * slot);
+                    double2 r = *pr;
+                    if (!use_r || !inrow || pair >= pl) r = make_double2(0.0, 0.0);
+                    if (a.first_bad != nullptr && a.check_rin && pair < kThreads * PPT && t < n) {
+                        const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
+                        if (!finite_f64(r.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                        if (!finite_f64(r.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                    }
+                    *pr = r;
+                }
+            }
+        }
+        lds_barrier();  // every wave's part of W_j has landed, R_j is written
+
+        const int pe = (j > a.lev0) ? a.pend[j - 1] : T;  // the last level only needs the tile
+        const bool hact = (T + 128 * wave) < pe;
+        const int ph_own = kThreads * PPT + tid;
+        const bool hwr = 2 * ph_own < pe;
+        const int ph = hwr ? ph_own : (pe >> 1) - 1;
+        double acc[NP][2];
+        int P0 = 0;
+        acc[4][0] = acc[4][1] = 0.0;
+        if (VW_ABLATED(a, 0)) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc[k][0] = acc[k][1] = 1.0;
+            P0 = ((tid >> (S < 0 ? 0 : S)) << ((S < 0 ? 0 : S) + 2)) + (tid & ((1 << (S < 0 ? 0 : S)) - 1));
+        } else
+#define VW_RING_LEVEL(SS, SLOT)                                                                         \
+    inv_blk_main<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, tid, S, tl, th, acc, P0);              \
+    if (hact) inv_blk_halo<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, ph, S, tl, th, acc);
+        switch (j) {
+            case 1: inv_blk_level1<LT, FMA, (1 + 1) * kRingBand, true>(lds, tid, tl, th, acc); break;
+            case 2: VW_RING_LEVEL(0, 2) break;
+            case 3: VW_RING_LEVEL(1, 0) break;
+            case 4: VW_RING_LEVEL(2, 1) break;
+            case 5: VW_RING_LEVEL(3, 2) break;
+            case 6: VW_RING_LEVEL(4, 0) break;
+            case 7: VW_RING_LEVEL(4, 1) break;
+            default: VW_RING_LEVEL(4, 2) break;  // level 8
+        }
+#undef VW_RING_LEVEL
+        const int sp = (j >= 2) ? (1 << S) : 0;
+
+        if (j == a.lev0) {
+            double* __restrict__ orow = a.rout + row * a.rout_stride;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int pair = (j == 1) ? k * kThreads + tid : P0 + k * sp;
+                const int64_t t = t0 + 2 * pair;
+                if (t < a.n_store) gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
+            }
+        } else {
+            lds_barrier();  // every lane has finished reading R_j / W_j
+            // R_{j-1} in the layout of level j-1 (j > lev0 >= 1: a blocked level wrote these accumulators)
+            switch (j) {
+                case 2: ring_writeback<-1, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+                case 3: ring_writeback<0, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+                case 4: ring_writeback<1, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+                case 5: ring_writeback<2, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+                case 6: ring_writeback<3, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+                default: ring_writeback<4, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n); break;
+            }
+        }
+    }
+}
+
 // streaming inverse for long contexts: mirror image of k_fwd_sdry
 // ---------------------------------------------------------------------------
 //

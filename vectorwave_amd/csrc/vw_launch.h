@@ -28,6 +28,11 @@ constexpr SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
 // unroll: filters of exactly 8 + 8 taps take the fully unrolled tap loop
 hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+// register-blocked inverse (k_inv_blk): shape (4 tile chunks, 1 halo chunk) only, see inv_blk_supported
+bool inv_blk_supported(int taps, int top_level);
+hipError_t launch_inv_blk(const InvArgs& a, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+// the same with the bands fed by LDS-DMA (k_inv_ring): additionally needs 16-byte-aligned rows and n >= 2560
+hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 

@@ -31,6 +31,48 @@ hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool f
 }
 
 
+// register-blocked tile kernel: both reconstruction filters walked over exactly LT taps
+template <int LT, int MODE>
+static hipError_t launch_inv_blk_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vec2) return fma ? launch_tile(k_inv_blk<LT, MODE, true, true>, a, nblocks, lds, stream)
+                         : launch_tile(k_inv_blk<LT, MODE, true, false>, a, nblocks, lds, stream);
+    return fma ? launch_tile(k_inv_blk<LT, MODE, false, true>, a, nblocks, lds, stream)
+               : launch_tile(k_inv_blk<LT, MODE, false, false>, a, nblocks, lds, stream);
+}
+bool inv_blk_supported(int taps, int top_level) { return (taps == 2 || taps == 4 || taps == 8) && top_level <= 8; }
+#define VW_INV_BLK_CASE(LT)                                                                                   \
+    if (a.lh == LT)                                                                                           \
+        return mode == kPeriodic ? launch_inv_blk_pm<LT, kPeriodic>(a, vec2, fma, nblocks, lds, stream)       \
+                                 : launch_inv_blk_pm<LT, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+hipError_t launch_inv_blk(const InvArgs& a, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream) {
+    const size_t lds = 2 * static_cast<size_t>(kBlkWOff);
+    VW_INV_BLK_CASE(2)
+    VW_INV_BLK_CASE(4)
+    VW_INV_BLK_CASE(8)
+    return hipErrorInvalidValue;
+}
+
+// LDS-DMA ring form of the register-blocked kernel (16-byte-aligned rows only)
+template <int LT, int MODE>
+static hipError_t launch_inv_ring_pm(const InvArgs& a, bool fma, bool plain, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (plain) return fma ? launch_tile(k_inv_ring<LT, MODE, true, true>, a, nblocks, lds, stream)
+                          : launch_tile(k_inv_ring<LT, MODE, false, true>, a, nblocks, lds, stream);
+    return fma ? launch_tile(k_inv_ring<LT, MODE, true, false>, a, nblocks, lds, stream)
+               : launch_tile(k_inv_ring<LT, MODE, false, false>, a, nblocks, lds, stream);
+}
+#define VW_INV_RING_CASE(LT)                                                                                  \
+    if (a.lh == LT)                                                                                           \
+        return mode == kPeriodic ? launch_inv_ring_pm<LT, kPeriodic>(a, fma, plain, nblocks, lds, stream)     \
+                                 : launch_inv_ring_pm<LT, kZeroPad>(a, fma, plain, nblocks, lds, stream);
+hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
+    const size_t lds = 4 * static_cast<size_t>(kRingBand);
+    const bool plain = a.thr_mode == 0 && a.first_bad == nullptr && a.band_mask == 0xffffffffu;
+    VW_INV_RING_CASE(2)
+    VW_INV_RING_CASE(4)
+    VW_INV_RING_CASE(8)
+    return hipErrorInvalidValue;
+}
+
 template <int NT, int P, int HB, int MODE>
 static hipError_t launch_inv_sdry_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
     if (vec2) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
