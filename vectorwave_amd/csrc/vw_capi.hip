@@ -46,6 +46,10 @@ struct PlanOptions {
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
     int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
     int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
+    int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
+    int inv_vm = 0;                      // global access mode of the long-context inverse: 0 one sample per access
+                                         // (measured 6 % faster than pairs, aligned or not), 1 / 2 pairs, -1 by alignment
+    int no_vec2 = 0;                     // 1: the inverse tile kernels access global memory one sample at a time
 #ifdef VW_TUNING
     char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
 #endif
@@ -185,6 +189,12 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_blk = value != 0;
     } else if (strcmp(name, "no_ring") == 0) {
         o.no_ring = value != 0;
+    } else if (strcmp(name, "no_wide_inv") == 0) {
+        o.no_wide_inv = value != 0;
+    } else if (strcmp(name, "inv_vm") == 0) {
+        o.inv_vm = (value >= 0 && value <= 2) ? static_cast<int>(value) : -1;
+    } else if (strcmp(name, "no_vec2") == 0) {
+        o.no_vec2 = value != 0;
     } else {
         return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
     }
@@ -196,7 +206,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring"};
+                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "no_wide_inv", "inv_vm", "no_vec2"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -480,7 +490,14 @@ static int plan_sdry(const vw_ctx* ctx, int lev0, int lev1, int lmax, bool inver
         if (hl > hmax) hmax = hl;
     }
     if (ctx->opt.no_sdry) return 0;
-    for (int v = 1; v <= 2; ++v) {
+    // the inverse prefers the sixteen-wave shape when it fits: its LDS need (two buffers, two history sets) leaves room
+    // for one workgroup per CU either way
+    static const int kOrderFwd[] = {1, 2}, kOrderInv[] = {3, 1, 2};
+    const int* order = inverse ? kOrderInv : kOrderFwd;
+    const int norder = inverse ? 3 : 2;
+    for (int oi = 0; oi < norder; ++oi) {
+        const int v = order[oi];
+        if (v == 3 && ctx->opt.no_wide_inv) continue;
         const SdryShape& sh = kSdry[v];
         const int64_t halo = static_cast<int64_t>(sh.hb) * kChunk;
         if (hmax > halo - 2 || hmax > sh.tile()) continue;
@@ -497,10 +514,11 @@ static int plan_sdry(const vw_ctx* ctx, int lev0, int lev1, int lmax, bool inver
 
 // Run length of the long-context kernels: long enough to amortise the warm-up tiles, short enough to
 // fill the chip.  Plan option sdry_chunks overrides.
-static void sdry_runs(const PlanOptions& opt, int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out) {
+static void sdry_runs(const PlanOptions& opt, int64_t rows, int64_t tiles, int ndry, int32_t* nchunks, int32_t* nseg_out,
+                      int64_t want_runs = 1024) {
     // about 1024 runs in all: two 512-lane workgroups fit a CU, and longer runs amortise the warm-up tiles better
     // than a third and fourth wave of workgroups would (sym8 J=8 on 64 x 777777: 24-48 tiles per run measured best)
-    int64_t nseg = rows > 0 ? (1024 + rows - 1) / rows : 1;
+    int64_t nseg = rows > 0 ? (want_runs + rows - 1) / rows : 1;
     if (nseg > tiles) nseg = tiles;
     if (nseg < 1) nseg = 1;
     int64_t nch = (tiles + nseg - 1) / nseg;
@@ -679,7 +697,7 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t e = launch_fwd_sdry(a, st.sdry, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            hipError_t e = launch_fwd_sdry(a, st.sdry, boundary, vec2, (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
         } else if (st.fused) {
             FwdArgs a;
@@ -949,7 +967,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             const int T = kSdry[st.sdry].tile();
             const int64_t tiles = (n + T - 1) / T;
             a.tiles_per_row = static_cast<int32_t>(tiles);
-            sdry_runs(ctx->opt, b, tiles, st.ndry, &a.nchunks, &a.ntiles);
+            // the sixteen-wave shape runs one workgroup per CU: half as many runs fill the chip equally often
+            sdry_runs(ctx->opt, b, tiles, st.ndry, &a.nchunks, &a.ntiles, st.sdry == 3 ? 512 : 1024);
             a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
             a.thr_mode = thr_mode;
             a.thr = thr_rows;
@@ -966,7 +985,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t e = launch_inv_sdry(a, st.sdry, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+            hipError_t e = launch_inv_sdry(a, st.sdry, boundary, ctx->opt.inv_vm >= 0 ? (ctx->opt.inv_vm == 1 && !vec2 ? 2 : ctx->opt.inv_vm) : (vec2 ? 1 : 2), (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(e));
         } else if (st.fused) {
             InvArgs a;
@@ -1012,7 +1031,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (strstr(ctx->opt.ablate, "ringnomath")) a.ablate |= 1;
             if (strstr(ctx->opt.ablate, "ringnoload")) a.ablate |= 2;
 #endif
-            const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
+            const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout) &&
+                              !ctx->opt.no_vec2;
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
             const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1);

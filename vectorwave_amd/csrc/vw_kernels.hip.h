@@ -135,6 +135,69 @@ __device__ __forceinline__ void gstore2(double* p, double2 v, int nt) {
     }
 }
 
+// Global access modes of the long-context kernels (template parameter VEC2 there): 0 = one sample per access,
+// 1 = 16-byte accesses (even n, 16-byte-aligned rows), 2 = 16-byte accesses at 8-byte alignment.  Mode 2 serves odd
+// row lengths, where every second row starts 8 bytes off: gfx950 executes a dwordx4 global access at any dword
+// alignment, so only the pair that straddles the end of the row needs the one-sample form.
+typedef double vw_f64x2u __attribute__((ext_vector_type(2), aligned(8)));
+template <int VM>
+__device__ __forceinline__ double2 gload_pair(const double* __restrict__ row, int64_t t, int64_t n) {  // 0 <= t; zeros beyond n
+    double2 x = make_double2(0.0, 0.0);
+    if (VM == 1) {
+        if (t < n) x = *reinterpret_cast<const double2*>(row + t);
+    } else if (VM == 2) {
+        if (t + 1 < n) {
+            const vw_f64x2u v = *reinterpret_cast<const vw_f64x2u*>(row + t);
+            x.x = v.x;
+            x.y = v.y;
+        } else if (t < n) {
+            x.x = row[t];
+        }
+    } else {
+        if (t < n) x.x = row[t];
+        if (t + 1 < n) x.y = row[t + 1];
+    }
+    return x;
+}
+__device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n);
+template <int VM>
+__device__ __forceinline__ double2 gload_pair_wrapped(const double* __restrict__ row, int64_t t, int64_t n) {  // any t, periodic
+    double2 x;
+    const int64_t tw = mod_wrap(t, n);
+    if (VM == 1) {
+        x = *reinterpret_cast<const double2*>(row + tw);
+    } else if (VM == 2 && tw + 1 < n) {
+        const vw_f64x2u v = *reinterpret_cast<const vw_f64x2u*>(row + tw);
+        x.x = v.x;
+        x.y = v.y;
+    } else {
+        x.x = row[tw];
+        x.y = row[tw + 1 < n ? tw + 1 : mod_wrap(t + 1, n)];
+    }
+    return x;
+}
+template <int VM>
+__device__ __forceinline__ void gstore_pair(double* __restrict__ row, int64_t t, int64_t ns, double v0, double v1, int nt) {
+    if (VM == 1) {
+        if (t < ns) gstore2(row + t, make_double2(v0, v1), nt);
+    } else if (VM == 2) {
+        if (t + 1 < ns) {
+            vw_f64x2u x;
+            x.x = v0;
+            x.y = v1;
+            if (nt)
+                __builtin_nontemporal_store(x, reinterpret_cast<vw_f64x2u*>(row + t));
+            else
+                *reinterpret_cast<vw_f64x2u*>(row + t) = x;
+        } else if (t < ns) {
+            row[t] = v0;
+        }
+    } else {
+        if (t < ns) row[t] = v0;
+        if (t + 1 < ns) row[t + 1] = v1;
+    }
+}
+
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -649,7 +712,7 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
 // is not special either: the run simply starts `ndry` tiles early with the stores switched off.  The
 // cascade is FIR, so after sum_j (L-1) 2^(j-1) samples every history holds exact values, whatever it
 // held before.  Histories: hlen[j] <= min(T, HB*512) samples of V_{j-1} per level in LDS.
-template <int NT, int PPT, int HB, int MODE, bool VEC2, bool FMA>
+template <int NT, int PPT, int HB, int MODE, int VEC2, bool FMA, int LT = 0>
 __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
     extern __shared__ double2 vw_smem[];
     constexpr int HALO = HB * kChunk;
@@ -682,21 +745,10 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
         for (int k = 0; k < PPT; ++k) {
             const int64_t t = t0 + k * CH + 2 * tid;
             double2 x = make_double2(0.0, 0.0);
-            if (t >= 0) {
-                if (VEC2) {
-                    if (t < n) x = *reinterpret_cast<const double2*>(inrow + t);
-                } else {
-                    if (t < n) x.x = inrow[t];
-                    if (t + 1 < n) x.y = inrow[t + 1];
-                }
-            } else if (MODE == kPeriodic) {
-                if (VEC2) {
-                    x = *reinterpret_cast<const double2*>(inrow + mod_wrap(t, n));
-                } else {
-                    x.x = inrow[mod_wrap(t, n)];
-                    x.y = inrow[mod_wrap(t + 1, n)];
-                }
-            }
+            if (t >= 0)
+                x = gload_pair<VEC2>(inrow, t, n);
+            else if (MODE == kPeriodic)
+                x = gload_pair_wrapped<VEC2>(inrow, t, n);
             v[k] = x;
         }
     };
@@ -745,9 +797,9 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
             const int hbase[1] = {0};
             const char* lds = reinterpret_cast<const char*>(buf);
             if (s == 1)
-                fwd_level<PPT, 1, true, FMA, CH, 0, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
+                fwd_level<PPT, 1, true, FMA, CH, LT, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
             else
-                fwd_level<PPT, 1, false, FMA, CH, 0, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
+                fwd_level<PPT, 1, false, FMA, CH, LT, HALO>(lds, a, s, tid, av, aw, ah, hbase, wact);
 
             if (!dry) {
                 double* __restrict__ wrow =
@@ -755,12 +807,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const int64_t t = t0 + k * CH + 2 * tid;
-                    if (VEC2) {
-                        if (t < ns) gstore2(wrow + t, make_double2(aw[k][0], aw[k][1]), a.nt_store);
-                    } else {
-                        if (t < ns) wrow[t] = aw[k][0];
-                        if (t + 1 < ns) wrow[t + 1] = aw[k][1];
-                    }
+                    gstore_pair<VEC2>(wrow, t, ns, aw[k][0], aw[k][1], a.nt_store);
                 }
             }
             if (j == a.lev1) {
@@ -769,12 +816,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int64_t t = t0 + k * CH + 2 * tid;
-                        if (VEC2) {
-                            if (t < ns) gstore2(vrow + t, make_double2(av[k][0], av[k][1]), a.nt_store);
-                        } else {
-                            if (t < ns) vrow[t] = av[k][0];
-                            if (t + 1 < ns) vrow[t + 1] = av[k][1];
-                        }
+                        gstore_pair<VEC2>(vrow, t, ns, av[k][0], av[k][1], a.nt_store);
                     }
                 }
                 if (ch + 1 < ntl) lds_barrier();  // last reads of this tile done before it is restaged
@@ -845,7 +887,9 @@ __device__ __forceinline__ void inv_mac(double flo, double fhi, const double2 (&
 }
 
 // One level of one tile: taps in ascending order, the next tap's filter values fetched one ahead.
-template <int PPT, int NP, bool S1, bool FMA>
+// LT > 0: the loop bound is exactly LT; the tap loop is unrolled completely with all 2*LT tap values fetched up
+// front, so that no scalar load (which shares its completion counter with the LDS reads) sits inside it.
+template <int PPT, int NP, bool S1, bool FMA, int LT = 0>
 __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, const InvArgs& a, int s,
                                           double (&acc)[NP][2], const int (&pb)[NP], const bool (&wact)[NP]) {
     const int lh = a.lh;
@@ -859,6 +903,20 @@ __device__ __forceinline__ void inv_level(const char* ldsR, const char* ldsW, co
             r[k].y = *reinterpret_cast<const double*>(ldsR + pb[k]);
             w[k].y = *reinterpret_cast<const double*>(ldsW + pb[k]);
         }
+    }
+    if (LT > 0) {
+        double tl[LT > 0 ? LT : 1], th[LT > 0 ? LT : 1];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) {
+            tl[i] = a.taps.lo[i];
+            th[i] = a.taps.hi[i];
+        }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            inv_read<PPT, NP, S1>(ldsR, ldsW, pb, l * sb, wact, r, w, r, w);
+            inv_mac<PPT, NP, FMA>(tl[l], th[l], r, w, wact, acc);
+        }
+        return;
     }
     // any length: one tap per trip, the next tap's filter values fetched one ahead
     int off = 0;
@@ -1586,7 +1644,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
 // kept in LDS; the run starts `ndry` tiles to the right of its last tile with the stores switched off,
 // after which every history is exact (FIR cascade).  While a level is computed, the next detail band
 // (or, at the last level, the next tile's R and first detail band) is in flight from HBM.
-template <int NT, int PPT, int HB, int MODE, bool VEC2, bool FMA>
+template <int NT, int PPT, int HB, int MODE, int VEC2, bool FMA, int LT = 0>
 __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
     extern __shared__ double2 vw_smem[];
     constexpr int HALO = HB * kChunk;
@@ -1624,21 +1682,10 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
             const int64_t t = t0 + k * CH + 2 * tid;
             double2 x = make_double2(0.0, 0.0);
             if (use) {
-                if (VEC2) {
-                    if (t < n)
-                        x = *reinterpret_cast<const double2*>(src + t);
-                    else if (MODE == kPeriodic)
-                        x = *reinterpret_cast<const double2*>(src + mod_wrap(t, n));
-                } else {
-                    if (t < n)
-                        x.x = src[t];
-                    else if (MODE == kPeriodic)
-                        x.x = src[mod_wrap(t, n)];
-                    if (t + 1 < n)
-                        x.y = src[t + 1];
-                    else if (MODE == kPeriodic)
-                        x.y = src[mod_wrap(t + 1, n)];
-                }
+                if (t + 1 < n || MODE != kPeriodic)
+                    x = gload_pair<VEC2>(src, t, n);
+                else
+                    x = gload_pair_wrapped<VEC2>(src, t, n);
             }
             v[k] = x;
         }
@@ -1729,9 +1776,9 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) acc[k][0] = acc[k][1] = 0.0;
             if (s == 1)
-                inv_level<PPT, PPT, true, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
+                inv_level<PPT, PPT, true, FMA, LT>(ldsR, ldsW, a, s, acc, pb, wact);
             else
-                inv_level<PPT, PPT, false, FMA>(ldsR, ldsW, a, s, acc, pb, wact);
+                inv_level<PPT, PPT, false, FMA, LT>(ldsR, ldsW, a, s, acc, pb, wact);
 
             if (j == a.lev0) {
                 if (!dry) {
@@ -1739,13 +1786,7 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
 #pragma unroll
                     for (int k = 0; k < PPT; ++k) {
                         const int64_t t = t0 + k * CH + 2 * tid;
-                        if (VEC2) {
-                            if (t < a.n_store)
-                                gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
-                        } else {
-                            if (t < a.n_store) orow[t] = acc[k][0];
-                            if (t + 1 < a.n_store) orow[t + 1] = acc[k][1];
-                        }
+                        gstore_pair<VEC2>(orow, t, a.n_store, acc[k][0], acc[k][1], a.nt_store);
                     }
                 }
                 if (ch + 1 < ntl) lds_barrier();  // last reads of this tile done before it is restaged

@@ -22,7 +22,9 @@ struct SdryShape {
     int nt, ppt, hb;
     int tile() const { return ppt * 2 * nt; }
 };
-constexpr SdryShape kSdry[3] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}};
+// shape 3 (inverse only): 1024 lanes, 4096-sample tiles -- R and W buffers plus both history sets fill the 160 KiB of
+// a CU exactly, one workgroup of sixteen waves per CU instead of one of eight
+constexpr SdryShape kSdry[4] = {{0, 0, 0}, {512, 2, 4}, {512, 4, 5}, {1024, 2, 4}};
 
 
 // unroll: filters of exactly 8 + 8 taps take the fully unrolled tap loop
@@ -33,8 +35,9 @@ bool inv_blk_supported(int taps, int top_level);
 hipError_t launch_inv_blk(const InvArgs& a, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 // the same with the bands fed by LDS-DMA (k_inv_ring): additionally needs 16-byte-aligned rows and n >= 2560
 hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
-hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
-hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
+hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
+// vec2: global access mode (0 one sample per access, 1 aligned pairs, 2 pairs at 8-byte alignment)
+hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, int vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 
 // shared by the launcher units
 template <typename K, typename A>

@@ -50,15 +50,30 @@ hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool f
 
 template <int NT, int P, int HB, int MODE>
 static hipError_t launch_fwd_sdry_pm(const FwdArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
-                         : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
-    return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
-               : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
+    if (vec2) return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, 1, true>, a, NT, nblocks, lds, stream)
+                         : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, 1, false>, a, NT, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, 2, true>, a, NT, nblocks, lds, stream)
+               : launch_tile_nt(k_fwd_sdry<NT, P, HB, MODE, 2, false>, a, NT, nblocks, lds, stream);
 }
-hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
-                                  hipStream_t stream) {
+template <int LT, int MODE>
+static hipError_t launch_fwd_sdry_lt(const FwdArgs& a, bool vec2, int64_t nblocks, size_t lds, hipStream_t stream) {
+    return vec2 ? launch_tile_nt(k_fwd_sdry<512, 2, 4, MODE, 1, false, LT>, a, 512, nblocks, lds, stream)
+                : launch_tile_nt(k_fwd_sdry<512, 2, 4, MODE, 2, false, LT>, a, 512, nblocks, lds, stream);
+}
+#define VW_FWD_SDRY_LT(LT)                                                                          \
+    if (a.lh == LT)                                                                                 \
+        return mode == kPeriodic ? launch_fwd_sdry_lt<LT, kPeriodic>(a, vec2, nblocks, lds, stream) \
+                                 : launch_fwd_sdry_lt<LT, kZeroPad>(a, vec2, nblocks, lds, stream);
+hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks,
+                           hipStream_t stream) {
     const SdryShape& sh = kSdry[shape];
     const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8;
+    // reference arithmetic, both filters of exactly 16 / 18 / 20 taps (sym8, coif3, db10 ...): fully unrolled tap loop
+    if (shape == 1 && !fma && a.lh == a.lg && unroll) {
+        VW_FWD_SDRY_LT(16)
+        VW_FWD_SDRY_LT(18)
+        VW_FWD_SDRY_LT(20)
+    }
     if (shape == 1)
         return mode == kPeriodic ? launch_fwd_sdry_pm<512, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
                                  : launch_fwd_sdry_pm<512, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);

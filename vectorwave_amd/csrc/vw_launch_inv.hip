@@ -73,15 +73,28 @@ hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks
     return hipErrorInvalidValue;
 }
 
+// vm: global access mode of the kernel (0 one sample, 1 aligned pairs, 2 pairs at 8-byte alignment)
 template <int NT, int P, int HB, int MODE>
-static hipError_t launch_inv_sdry_pm(const InvArgs& a, bool vec2, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
-    if (vec2) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, true>, a, NT, nblocks, lds, stream)
-                         : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, true, false>, a, NT, nblocks, lds, stream);
-    return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, true>, a, NT, nblocks, lds, stream)
-               : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, false, false>, a, NT, nblocks, lds, stream);
+static hipError_t launch_inv_sdry_pm(const InvArgs& a, int vm, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vm == 1) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 1, true>, a, NT, nblocks, lds, stream)
+                            : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 1, false>, a, NT, nblocks, lds, stream);
+    if (vm == 2) return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 2, true>, a, NT, nblocks, lds, stream)
+                            : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 2, false>, a, NT, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 0, true>, a, NT, nblocks, lds, stream)
+               : launch_tile_nt(k_inv_sdry<NT, P, HB, MODE, 0, false>, a, NT, nblocks, lds, stream);
 }
-hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, bool fma, int64_t nblocks,
-                                  hipStream_t stream) {
+template <int LT, int MODE>
+static hipError_t launch_inv_sdry_lt(const InvArgs& a, int vm, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (vm == 1) return launch_tile_nt(k_inv_sdry<1024, 2, 4, MODE, 1, false, LT>, a, 1024, nblocks, lds, stream);
+    if (vm == 2) return launch_tile_nt(k_inv_sdry<1024, 2, 4, MODE, 2, false, LT>, a, 1024, nblocks, lds, stream);
+    return launch_tile_nt(k_inv_sdry<1024, 2, 4, MODE, 0, false, LT>, a, 1024, nblocks, lds, stream);
+}
+#define VW_INV_SDRY_LT(LT)                                                                          \
+    if (a.lh == LT)                                                                                 \
+        return mode == kPeriodic ? launch_inv_sdry_lt<LT, kPeriodic>(a, vec2, nblocks, lds, stream) \
+                                 : launch_inv_sdry_lt<LT, kZeroPad>(a, vec2, nblocks, lds, stream);
+hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, int vec2, bool fma, bool unroll, int64_t nblocks,
+                           hipStream_t stream) {
     const SdryShape& sh = kSdry[shape];
     const size_t lds = static_cast<size_t>(sh.hb * kChunk + sh.tile() + a.hist_cap) * 8 * 2;
     if (shape == 1)
@@ -90,6 +103,14 @@ hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, bool vec2, boo
     if (shape == 2)
         return mode == kPeriodic ? launch_inv_sdry_pm<512, 4, 5, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
                                  : launch_inv_sdry_pm<512, 4, 5, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+    if (shape == 3 && !fma && unroll) {
+        VW_INV_SDRY_LT(16)
+        VW_INV_SDRY_LT(18)
+        VW_INV_SDRY_LT(20)
+    }
+    if (shape == 3)
+        return mode == kPeriodic ? launch_inv_sdry_pm<1024, 2, 4, kPeriodic>(a, vec2, fma, nblocks, lds, stream)
+                                 : launch_inv_sdry_pm<1024, 2, 4, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
     return hipErrorInvalidValue;
 }
 
