@@ -34,7 +34,8 @@ def noalloc_denoise(ctx, x_t, wname, levels, boundary, threshold, soft):
 
 
 @pytest.mark.parametrize("wname,levels,boundary,first,second,threshold,soft", [
-    ("db4", 4, 0, (8192, 480), (1000, 480), -1.0, True),     # the streaming-block shape fills the array almost whole
+    ("db4", 4, 0, (8192, 480), (1000, 480), -1.0, True),     # the streaming-block shape: row-resident kernel, no scratch
+    ("db4", 4, 0, (1000, 4096), (100, 2500), -1.0, True),    # rows too long for it: 156 MiB of the array, then a small call
     ("db4", 6, 0, (64, 16384), (3, 5000), -1.0, True),       # tile kernels, then a smaller batch of shorter rows
     ("sym8", 8, 1, (6, 20000), (2, 9000), 0.25, False),      # long-context kernels, fixed threshold, hard rule
     ("coif3", 7, 0, (5, 12288), (5, 3000), -1.0, True),
@@ -75,7 +76,7 @@ def test_multi_pass_plan_borrows_its_plane_from_the_array(ctx, plan):
 def test_sizes_beyond_the_static_array_are_refused(ctx):
     import torch
     limit = 160 << 20
-    b, n, levels = 8192, 512, 4  # 8192 * 5 * 512 * 8 = 160 MiB of coefficients + thresholds: just over
+    b, n, levels = 1024, 4096, 4  # 1024 * 5 * 4096 * 8 = 160 MiB of coefficients + thresholds: just over
     assert ctx.lib.vw_swt_denoise_workspace_bytes(b, n, levels) > limit
     x_t = torch.zeros((b, n), dtype=torch.float64, device="cuda")
     st, out, _ = noalloc_denoise(ctx, x_t, "db4", levels, 0, -1.0, True)

@@ -511,6 +511,525 @@ __global__ void __launch_bounds__(64) k_universal_threshold_reg(const MedianArgs
 }
 
 // ---------------------------------------------------------------------------
+// row-resident SWT denoise: forward cascade, exact median, thresholds, inverse cascade in one launch
+// ---------------------------------------------------------------------------
+//
+// VectorWaveSwtAdapter.denoise (swt/VectorWaveSwtAdapter.java:296-312) for rows short enough that the whole
+// decomposition of a row stays on chip: one wavefront per row, HBM traffic 16 bytes per sample (the row in, the
+// row out).  LDS per row: two signal buffers (running approximation, ping-pong) with a halo on either side, and
+// one buffer per detail band with a right halo.  The boundary rule is materialised in the halos -- copies of the
+// other end of the row (PERIODIC) or zeros (ZERO_PADDING) written after each level -- so the tap loops index
+// linearly, without a modulo.  A lane owns the pairs 2*(lane + 64*k); operands of dilated taps are aligned
+// 16-byte reads, the stride-one level reads its window as LT/2 + 1 aligned pairs.  The universal threshold is the
+// register-resident exact selection of k_universal_threshold_reg on |d_1| read back from LDS, so d_1 is
+// thresholded in place after it and the coarser bands as they are written.  No workgroup barrier exists:
+// the workgroup is the wavefront, whose LDS operations execute in order.
+// Needs: both decomposition filters and the low-pass reconstruction filter of exactly LT taps (LT even), the
+// reference's level limit (no filter longer than the row), n <= 64 * KPL.
+
+struct RowDenoiseArgs {
+    const double* x;   // rows of length n
+    int64_t x_stride;
+    double* y;
+    int64_t y_stride;
+    int64_t n;
+    int64_t nrows;
+    int32_t levels;
+    int32_t thr_mode;       // apply_thr mode: 1 soft, 2 hard
+    double threshold;       // >= 0 (or NaN): fixed; < 0: universal threshold from |d_1|
+    double sqrt_2_ln_n;
+    double* thr_out;        // [nrows] or nullptr
+    int32_t vec;            // rows are 16-byte aligned and n is even: 16-byte global accesses
+    Taps dec, rec;          // decomposition (lo = h, hi = g) and reconstruction (lo = h~, hi = g~) taps, scaled
+};
+
+template <int LT, int KPL, int MODE>
+__global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ double2 vw_smem[];
+    constexpr int KP = KPL / 2;          // pairs per lane
+    constexpr int G = KP < 2 ? KP : 2;   // pairs whose operand windows are requested together
+    constexpr int NW = LT / 2 + 1;       // aligned pairs in the window of a stride-one level
+    const int lane = threadIdx.x;
+    const int n = static_cast<int>(a.n);
+    const int J = a.levels;
+    const int np = (n + 1) & ~1;
+    const int hm = ((((LT - 1) << (J - 1)) + 1) & ~1) + 2;  // widest halo, even, with slack for the pair that straddles n
+    const int bs = hm + np + hm;                              // signal buffer: [left halo | row | right halo]
+    const int ws = np + hm;                                   // band buffer: [row | right halo]
+    double* lds = reinterpret_cast<double*>(vw_smem);
+    double* bufA = lds + hm;                                  // index 0 of the row
+    double* bufB = lds + bs + hm;
+    double* wband = lds + 2 * bs;                             // band j at wband + (j-1)*ws
+    const int64_t row = blockIdx.x;
+    const double* __restrict__ xrow = a.x + row * a.x_stride;
+
+    double dl[LT], dh[LT], rl[LT], rh[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        dl[l] = a.dec.lo[l];
+        dh[l] = a.dec.hi[l];
+        rl[l] = a.rec.lo[l];
+        rh[l] = a.rec.hi[l];
+    }
+
+    // halo writers: H samples (plus one for the straddling pair) of the other end of the row, or zeros
+    auto fill_left = [&](double* b, int H) {
+        for (int i = lane; i < H; i += 64) b[-1 - i] = (MODE == kPeriodic) ? b[n - 1 - i] : 0.0;
+    };
+    auto fill_right = [&](double* b, int H) {
+        for (int i = lane; i <= H; i += 64) b[n + i] = (MODE == kPeriodic) ? b[i] : 0.0;
+    };
+    // pair owned by this lane in chunk k; lanes beyond the row compute on its last pair and do not write
+    auto own = [&](int k, bool& live) {
+        const int p = 2 * (lane + 64 * k);
+        live = p < n;
+        return live ? p : np - 2;
+    };
+
+    // ---- the row -> bufA ------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int p = 2 * (lane + 64 * k);
+        if (p < n) {
+            double2 v;
+            if (a.vec) {
+                v = *reinterpret_cast<const double2*>(xrow + p);
+            } else {
+                v.x = xrow[p];
+                v.y = (p + 1 < n) ? xrow[p + 1] : 0.0;
+            }
+            *reinterpret_cast<double2*>(bufA + p) = v;
+        }
+    }
+    __syncthreads();
+    fill_left(bufA, LT - 1);
+    __syncthreads();
+
+    double thr = a.threshold;
+    double* in = bufA;
+    double* out = bufB;
+    // ---- forward cascade --------------------------------------------------------------------------------
+    for (int j = 1; j <= J; ++j) {
+        const int s = 1 << (j - 1);
+        double* wj = wband + (j - 1) * ws;
+        const bool thr_known = (j > 1) || !(a.threshold < 0);
+#pragma unroll
+        for (int k0 = 0; k0 < KP; k0 += G) {
+            bool live[G];
+            int p[G];
+            double av[G][2], aw[G][2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) p[g] = own(k0 + g, live[g]);
+            if (j == 1) {
+                // samples in[p - LT .. p + 1] as aligned pairs; tap l of output p reads in[p - l]
+                double2 xw[G][NW];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) xw[g][q] = *reinterpret_cast<const double2*>(in + p[g] - LT + 2 * q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    av[g][0] = av[g][1] = aw[g][0] = aw[g][1] = 0.0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        // in[p - l] is sample LT - l of the window, in[p + 1 - l] sample LT + 1 - l
+                        const int i0 = LT - l, i1 = LT + 1 - l;
+                        const double x0 = (i0 & 1) ? xw[g][i0 / 2].y : xw[g][i0 / 2].x;
+                        const double x1 = (i1 & 1) ? xw[g][i1 / 2].y : xw[g][i1 / 2].x;
+                        av[g][0] = av[g][0] + x0 * dl[l];
+                        av[g][1] = av[g][1] + x1 * dl[l];
+                        aw[g][0] = aw[g][0] + x0 * dh[l];
+                        aw[g][1] = aw[g][1] + x1 * dh[l];
+                    }
+                }
+            } else {
+                double2 xt[G][LT];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) xt[g][l] = *reinterpret_cast<const double2*>(in + p[g] - l * s);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    av[g][0] = av[g][1] = aw[g][0] = aw[g][1] = 0.0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        av[g][0] = av[g][0] + xt[g][l].x * dl[l];
+                        av[g][1] = av[g][1] + xt[g][l].y * dl[l];
+                        aw[g][0] = aw[g][0] + xt[g][l].x * dh[l];
+                        aw[g][1] = aw[g][1] + xt[g][l].y * dh[l];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (thr_known) {
+                    aw[g][0] = apply_thr(aw[g][0], thr, a.thr_mode);
+                    aw[g][1] = apply_thr(aw[g][1], thr, a.thr_mode);
+                }
+                if (live[g]) {
+                    *reinterpret_cast<double2*>(out + p[g]) = make_double2(av[g][0], av[g][1]);
+                    *reinterpret_cast<double2*>(wj + p[g]) = make_double2(aw[g][0], aw[g][1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (j == 1 && a.threshold < 0) {
+            // sigma = median(|d_1|) / 0.6745 with the order statistics a full sort would give
+            // (swt/VectorWaveSwtAdapter.java:377-395); thr = sigma * sqrt(2 ln n) (:263-264)
+            double v[KPL];
+#pragma unroll
+            for (int q = 0; q < KPL; ++q) {
+                const int i = q * 64 + lane;
+                v[q] = i < n ? fabs(wj[i]) : reg_pad();
+            }
+            const double median = reg_median<KPL>(v, a.n);
+            const double sigma = median / 0.6745;
+            thr = sigma * a.sqrt_2_ln_n;
+#pragma unroll
+            for (int q = 0; q < KPL; ++q) {
+                const int i = q * 64 + lane;
+                if (i < n) wj[i] = apply_thr(wj[i], thr, a.thr_mode);
+            }
+            __syncthreads();
+        }
+        // halos: the band's right halo for its inverse level; the approximation's left halo for the next forward
+        // level, or its right halo for the first inverse level
+        fill_right(wj, (LT - 1) * s);
+        if (j < J)
+            fill_left(out, (LT - 1) * 2 * s);
+        else
+            fill_right(out, (LT - 1) * s);
+        __syncthreads();
+        double* t = in;
+        in = out;
+        out = t;
+    }
+    if (a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
+
+    // ---- inverse cascade: `in` holds R_J ------------------------------------------------------------------
+    double* __restrict__ yrow = a.y + row * a.y_stride;
+    for (int j = J; j >= 1; --j) {
+        const int s = 1 << (j - 1);
+        const double* wj = wband + (j - 1) * ws;
+#pragma unroll
+        for (int k0 = 0; k0 < KP; k0 += G) {
+            bool live[G];
+            int p[G];
+            double r[G][2];
+#pragma unroll
+            for (int g = 0; g < G; ++g) p[g] = own(k0 + g, live[g]);
+            if (j == 1) {
+                double2 rw[G][NW], ww[G][NW];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        rw[g][q] = *reinterpret_cast<const double2*>(in + p[g] + 2 * q);
+                        ww[g][q] = *reinterpret_cast<const double2*>(wj + p[g] + 2 * q);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    r[g][0] = r[g][1] = 0.0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        const double a0 = (l & 1) ? rw[g][l / 2].y : rw[g][l / 2].x;
+                        const double a1 = (l & 1) ? rw[g][l / 2 + 1].x : rw[g][l / 2].y;
+                        const double d0 = (l & 1) ? ww[g][l / 2].y : ww[g][l / 2].x;
+                        const double d1 = (l & 1) ? ww[g][l / 2 + 1].x : ww[g][l / 2].y;
+                        r[g][0] = r[g][0] + (rl[l] * a0 + rh[l] * d0);
+                        r[g][1] = r[g][1] + (rl[l] * a1 + rh[l] * d1);
+                    }
+                }
+            } else {
+                double2 rt[G][LT], wt[G][LT];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        rt[g][l] = *reinterpret_cast<const double2*>(in + p[g] + l * s);
+                        wt[g][l] = *reinterpret_cast<const double2*>(wj + p[g] + l * s);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    r[g][0] = r[g][1] = 0.0;
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        r[g][0] = r[g][0] + (rl[l] * rt[g][l].x + rh[l] * wt[g][l].x);
+                        r[g][1] = r[g][1] + (rl[l] * rt[g][l].y + rh[l] * wt[g][l].y);
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (live[g]) {
+                    if (j == 1) {
+                        if (a.vec) {
+                            *reinterpret_cast<double2*>(yrow + p[g]) = make_double2(r[g][0], r[g][1]);
+                        } else {
+                            yrow[p[g]] = r[g][0];
+                            if (p[g] + 1 < n) yrow[p[g] + 1] = r[g][1];
+                        }
+                    } else {
+                        *reinterpret_cast<double2*>(out + p[g]) = make_double2(r[g][0], r[g][1]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j > 1) {
+            __syncthreads();
+            fill_right(out, (LT - 1) * (s >> 1));
+            __syncthreads();
+            double* t = in;
+            in = out;
+            out = t;
+        }
+    }
+}
+
+// The same for rows of at most 512 samples and at most four levels (the streaming-block shape): the detail bands
+// stay in REGISTERS between the forward and the inverse cascade (4 levels x 4 pairs per lane = 64 registers) and
+// pass through one LDS band buffer only while their inverse level runs; the running approximation is updated in
+// place (the forward looks left, so its chunks are taken right to left; the inverse the other way round).  LDS per
+// row drops from about 26 KiB to 9 KiB, i.e. from 6 to 12 resident rows per CU (then bounded by registers).
+template <int LT, int MODE>
+__global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ double2 vw_smem[];
+    constexpr int KP = 4, JMAX = 4;
+    constexpr int GF = (LT > 4) ? 1 : 2;  // forward chunks whose operand windows are requested together (registers)
+    constexpr int NW = LT / 2 + 1;
+    const int lane = threadIdx.x;
+    const int n = static_cast<int>(a.n);
+    const int J = a.levels;
+    const int np = (n + 1) & ~1;
+    const int hm = ((((LT - 1) << (J - 1)) + 1) & ~1) + 2;
+    double* lds = reinterpret_cast<double*>(vw_smem);
+    double* sig = lds + hm;               // [left halo | row | right halo]
+    double* wb = lds + hm + np + hm;      // [row | right halo]
+    const int64_t row = blockIdx.x;
+    const double* __restrict__ xrow = a.x + row * a.x_stride;
+
+    double dl[LT], dh[LT], rl[LT], rh[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        dl[l] = a.dec.lo[l];
+        dh[l] = a.dec.hi[l];
+        rl[l] = a.rec.lo[l];
+        rh[l] = a.rec.hi[l];
+    }
+    auto fill_left = [&](double* b, int H) {
+        for (int i = lane; i < H; i += 64) b[-1 - i] = (MODE == kPeriodic) ? b[n - 1 - i] : 0.0;
+    };
+    auto fill_right = [&](double* b, int H) {
+        for (int i = lane; i <= H; i += 64) b[n + i] = (MODE == kPeriodic) ? b[i] : 0.0;
+    };
+    int p[KP];
+    bool live[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int q = 2 * (lane + 64 * k);
+        live[k] = q < n;
+        p[k] = live[k] ? q : np - 2;  // lanes beyond the row compute on its last pair and do not write
+    }
+
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (live[k]) {
+            double2 v;
+            if (a.vec) {
+                v = *reinterpret_cast<const double2*>(xrow + p[k]);
+            } else {
+                v.x = xrow[p[k]];
+                v.y = (p[k] + 1 < n) ? xrow[p[k] + 1] : 0.0;
+            }
+            *reinterpret_cast<double2*>(sig + p[k]) = v;
+        }
+    }
+    __syncthreads();
+    fill_left(sig, LT - 1);
+    __syncthreads();
+
+    double thr = a.threshold;
+    double wreg[JMAX][KP][2];
+    // ---- forward cascade, in place, chunk groups right to left ---------------------------------------------
+#pragma unroll
+    for (int j = 1; j <= JMAX; ++j) {
+        if (j <= J) {
+            const int s = 1 << (j - 1);
+            const bool thr_known = (j > 1) || !(a.threshold < 0);
+#pragma unroll
+            for (int k0 = KP - GF; k0 >= 0; k0 -= GF) {
+                double av[GF][2];
+                if (j == 1) {
+                    double2 xw[GF][NW];
+#pragma unroll
+                    for (int g = 0; g < GF; ++g)
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) xw[g][q] = *reinterpret_cast<const double2*>(sig + p[k0 + g] - LT + 2 * q);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < GF; ++g) {
+                        double w0 = 0.0, w1 = 0.0;
+                        av[g][0] = av[g][1] = 0.0;
+#pragma unroll
+                        for (int l = 0; l < LT; ++l) {
+                            const int i0 = LT - l, i1 = LT + 1 - l;
+                            const double x0 = (i0 & 1) ? xw[g][i0 / 2].y : xw[g][i0 / 2].x;
+                            const double x1 = (i1 & 1) ? xw[g][i1 / 2].y : xw[g][i1 / 2].x;
+                            av[g][0] = av[g][0] + x0 * dl[l];
+                            av[g][1] = av[g][1] + x1 * dl[l];
+                            w0 = w0 + x0 * dh[l];
+                            w1 = w1 + x1 * dh[l];
+                        }
+                        wreg[j - 1][k0 + g][0] = w0;
+                        wreg[j - 1][k0 + g][1] = w1;
+                    }
+                } else {
+                    double2 xt[GF][LT];
+#pragma unroll
+                    for (int g = 0; g < GF; ++g)
+#pragma unroll
+                        for (int l = 0; l < LT; ++l) xt[g][l] = *reinterpret_cast<const double2*>(sig + p[k0 + g] - l * s);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < GF; ++g) {
+                        double w0 = 0.0, w1 = 0.0;
+                        av[g][0] = av[g][1] = 0.0;
+#pragma unroll
+                        for (int l = 0; l < LT; ++l) {
+                            av[g][0] = av[g][0] + xt[g][l].x * dl[l];
+                            av[g][1] = av[g][1] + xt[g][l].y * dl[l];
+                            w0 = w0 + xt[g][l].x * dh[l];
+                            w1 = w1 + xt[g][l].y * dh[l];
+                        }
+                        wreg[j - 1][k0 + g][0] = thr_known ? apply_thr(w0, thr, a.thr_mode) : w0;
+                        wreg[j - 1][k0 + g][1] = thr_known ? apply_thr(w1, thr, a.thr_mode) : w1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < GF; ++g)
+                    if (live[k0 + g]) *reinterpret_cast<double2*>(sig + p[k0 + g]) = make_double2(av[g][0], av[g][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j == 1) {
+                if (a.threshold < 0) {
+                    double v[2 * KP];
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const int q = 2 * (lane + 64 * k);
+                        v[2 * k] = q < n ? fabs(wreg[0][k][0]) : reg_pad();
+                        v[2 * k + 1] = q + 1 < n ? fabs(wreg[0][k][1]) : reg_pad();
+                    }
+                    const double median = reg_median<2 * KP>(v, a.n);
+                    const double sigma = median / 0.6745;
+                    thr = sigma * a.sqrt_2_ln_n;
+                }
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    wreg[0][k][0] = apply_thr(wreg[0][k][0], thr, a.thr_mode);
+                    wreg[0][k][1] = apply_thr(wreg[0][k][1], thr, a.thr_mode);
+                }
+            }
+            __syncthreads();
+            if (j < J)
+                fill_left(sig, (LT - 1) * 2 * s);
+            else
+                fill_right(sig, (LT - 1) * s);
+            __syncthreads();
+        }
+    }
+    if (a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
+
+    // ---- inverse cascade, in place, chunks left to right ------------------------------------------------------
+    double* __restrict__ yrow = a.y + row * a.y_stride;
+#pragma unroll
+    for (int j = JMAX; j >= 1; --j) {
+        if (j <= J) {
+            const int s = 1 << (j - 1);
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+                if (live[k]) *reinterpret_cast<double2*>(wb + p[k]) = make_double2(wreg[j - 1][k][0], wreg[j - 1][k][1]);
+            __syncthreads();
+            fill_right(wb, (LT - 1) * s);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                double r0 = 0.0, r1 = 0.0;
+                if (j == 1) {
+                    double2 rw[NW], ww[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        rw[q] = *reinterpret_cast<const double2*>(sig + p[k] + 2 * q);
+                        ww[q] = *reinterpret_cast<const double2*>(wb + p[k] + 2 * q);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        const double a0 = (l & 1) ? rw[l / 2].y : rw[l / 2].x;
+                        const double a1 = (l & 1) ? rw[l / 2 + 1].x : rw[l / 2].y;
+                        const double d0 = (l & 1) ? ww[l / 2].y : ww[l / 2].x;
+                        const double d1 = (l & 1) ? ww[l / 2 + 1].x : ww[l / 2].y;
+                        r0 = r0 + (rl[l] * a0 + rh[l] * d0);
+                        r1 = r1 + (rl[l] * a1 + rh[l] * d1);
+                    }
+                } else {
+                    // the window in two halves: with all four bands still in registers, sixteen operand pairs at once
+                    // would not fit the 128 registers that four waves per SIMD leave a lane
+                    constexpr int LH = (LT + 1) / 2;
+#pragma unroll
+                    for (int h0 = 0; h0 < LT; h0 += LH) {
+                        double2 rt[LH], wt[LH];
+#pragma unroll
+                        for (int l = 0; l < LH; ++l) {
+                            if (h0 + l < LT) {
+                                rt[l] = *reinterpret_cast<const double2*>(sig + p[k] + (h0 + l) * s);
+                                wt[l] = *reinterpret_cast<const double2*>(wb + p[k] + (h0 + l) * s);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int l = 0; l < LH; ++l) {
+                            if (h0 + l < LT) {
+                                r0 = r0 + (rl[h0 + l] * rt[l].x + rh[h0 + l] * wt[l].x);
+                                r1 = r1 + (rl[h0 + l] * rt[l].y + rh[h0 + l] * wt[l].y);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (live[k]) {
+                    if (j == 1) {
+                        if (a.vec) {
+                            *reinterpret_cast<double2*>(yrow + p[k]) = make_double2(r0, r1);
+                        } else {
+                            yrow[p[k]] = r0;
+                            if (p[k] + 1 < n) yrow[p[k] + 1] = r1;
+                        }
+                    } else {
+                        *reinterpret_cast<double2*>(sig + p[k]) = make_double2(r0, r1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j > 1) {
+                __syncthreads();
+                fill_right(sig, (LT - 1) * (s >> 1));
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // streaming denoiser: noise window, noise level and multiplier-path threshold, one workgroup per stream
 // ---------------------------------------------------------------------------
 //

@@ -49,6 +49,7 @@ struct PlanOptions {
     int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
     int inv_vm = 0;                      // global access mode of the long-context inverse: 0 one sample per access
                                          // (measured 6 % faster than pairs, aligned or not), 1 / 2 pairs, -1 by alignment
+    int no_band_regs = 0;                // 1: the row-resident denoise keeps every detail band in LDS
     int no_vec2 = 0;                     // 1: the inverse tile kernels access global memory one sample at a time
 #ifdef VW_TUNING
     char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
@@ -195,6 +196,8 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.inv_vm = (value >= 0 && value <= 2) ? static_cast<int>(value) : -1;
     } else if (strcmp(name, "no_vec2") == 0) {
         o.no_vec2 = value != 0;
+    } else if (strcmp(name, "no_band_regs") == 0) {
+        o.no_band_regs = value != 0;
     } else {
         return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
     }
@@ -206,7 +209,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "no_wide_inv", "inv_vm", "no_vec2"};
+                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -1350,6 +1353,76 @@ __global__ void __launch_bounds__(kThreads) k_threshold_rows(double* coeffs, int
 }
 
 static size_t round256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+// ---- row-resident SWT denoise (k_swt_denoise_row): one launch, no coefficient block ------------------------------
+
+static size_t row_denoise_lds(int64_t n, int levels, int lt) {
+    const int64_t np = (n + 1) & ~static_cast<int64_t>(1);
+    const int64_t hm = ((((static_cast<int64_t>(lt) - 1) << (levels - 1)) + 1) & ~static_cast<int64_t>(1)) + 2;
+    return static_cast<size_t>(2 * (hm + np + hm) + static_cast<int64_t>(levels) * (np + hm)) * 8;
+}
+
+static bool row_denoise_eligible(const vw_ctx* ctx, int64_t n, int levels, int lh, int lg, int lhr, int lgr, int boundary) {
+    if (ctx->opt.no_row_denoise) return false;
+    if (boundary != VW_BOUNDARY_PERIODIC && boundary != VW_BOUNDARY_ZERO_PADDING) return false;
+    if (!(lh == 2 || lh == 4 || lh == 8) || lg != lh || lhr != lh || lgr < lhr) return false;
+    if (n < 2 || n > 2048 || levels < 1 || levels > vw_max_levels(n, lh)) return false;
+    const size_t lds = row_denoise_lds(n, levels, lh);
+    return lds <= 65536 && lds <= static_cast<size_t>(ctx->lds_limit);
+}
+
+template <int LT, int MODE>
+static void launch_row_denoise_k(const RowDenoiseArgs& a, int64_t n, int64_t b, size_t lds, bool bands_in_regs, hipStream_t s) {
+    const dim3 grid(static_cast<unsigned>(b)), block(64);
+    if (bands_in_regs)
+        hipLaunchKernelGGL((k_swt_denoise_rowreg<LT, MODE>), grid, block, lds, s, a);
+    else if (n <= 256)
+        hipLaunchKernelGGL((k_swt_denoise_row<LT, 4, MODE>), grid, block, lds, s, a);
+    else if (n <= 512)
+        hipLaunchKernelGGL((k_swt_denoise_row<LT, 8, MODE>), grid, block, lds, s, a);
+    else if (n <= 1024)
+        hipLaunchKernelGGL((k_swt_denoise_row<LT, 16, MODE>), grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL((k_swt_denoise_row<LT, 32, MODE>), grid, block, lds, s, a);
+}
+
+static int row_denoise_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int levels, const double* h, int lh, const double* g,
+                           const double* hr, const double* gr, int boundary, double threshold, double sqrt_2_ln_n, int soft,
+                           double* y_dev, double* thresholds_out_dev, hipStream_t s) {
+    if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+    RowDenoiseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x_dev;
+    a.x_stride = n;
+    a.y = y_dev;
+    a.y_stride = n;
+    a.n = n;
+    a.nrows = b;
+    a.levels = levels;
+    a.thr_mode = soft ? 1 : 2;
+    a.threshold = threshold;
+    a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
+    a.thr_out = thresholds_out_dev;
+    a.vec = (n % 2 == 0) && aligned16(x_dev) && aligned16(y_dev);
+    scale_taps(h, lh, a.dec.lo);
+    scale_taps(g, lh, a.dec.hi);
+    scale_taps(hr, lh, a.rec.lo);
+    scale_taps(gr, lh, a.rec.hi);
+    // rows of up to 512 samples at up to four levels keep their detail bands in registers (one band buffer in LDS)
+    const bool regs = n <= 512 && levels <= 4 && !ctx->opt.no_band_regs;
+    const int64_t np = (n + 1) & ~static_cast<int64_t>(1);
+    const int64_t hm = ((((static_cast<int64_t>(lh) - 1) << (levels - 1)) + 1) & ~static_cast<int64_t>(1)) + 2;
+    const size_t lds = regs ? static_cast<size_t>(hm + np + hm + np + hm) * 8 : row_denoise_lds(n, levels, lh);
+    const bool per = boundary == VW_BOUNDARY_PERIODIC;
+    switch (lh) {
+        case 2: per ? launch_row_denoise_k<2, kPeriodic>(a, n, b, lds, regs, s) : launch_row_denoise_k<2, kZeroPad>(a, n, b, lds, regs, s); break;
+        case 4: per ? launch_row_denoise_k<4, kPeriodic>(a, n, b, lds, regs, s) : launch_row_denoise_k<4, kZeroPad>(a, n, b, lds, regs, s); break;
+        default: per ? launch_row_denoise_k<8, kPeriodic>(a, n, b, lds, regs, s) : launch_row_denoise_k<8, kZeroPad>(a, n, b, lds, regs, s); break;
+    }
+    VW_HIP(ctx, hipGetLastError());
+    return VW_OK;
+}
+
 static int swt_denoise_run(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int32_t levels, const double* h, int32_t lh,
                            const double* g, int32_t lg, const double* hr, int32_t lhr, const double* gr, int32_t lgr,
                            int32_t boundary, double threshold, double sqrt_2_ln_n, int32_t soft, double* y_dev,
@@ -1370,9 +1443,14 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
     VW_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t need = vw_swt_denoise_workspace_bytes(b, n, levels);
+    if (workspace_dev != nullptr && workspace_bytes < need)
+        return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
+    // short rows: the whole decomposition of a row stays in LDS, no workspace is touched
+    if (row_denoise_eligible(ctx, n, levels, lh, lg, lhr, lgr, boundary))
+        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+                               thresholds_out_dev, s);
     char* wsb;
     if (workspace_dev != nullptr) {
-        if (workspace_bytes < need) return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
         wsb = static_cast<char*>(workspace_dev);
     } else {
         rc = ensure(ctx, ctx->denoise_ws, need);
@@ -1396,6 +1474,13 @@ extern "C" int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx* ctx, const double* x
     rc = inverse_checks(ctx, x_dev, b, n, levels, hr, lhr, gr, lgr, boundary, 0, y_dev);
     if (rc != VW_OK) return rc;
     if (b == 0) return VW_OK;
+    if (row_denoise_eligible(ctx, n, levels, lh, lg, lhr, lgr, boundary)) {
+        // short rows need no scratch at all: the decomposition of a row never leaves LDS
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        VW_HIP(ctx, hipSetDevice(ctx->device));
+        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+                               thresholds_out_dev, static_cast<hipStream_t>(stream));
+    }
     const size_t need = round256(vw_swt_denoise_workspace_bytes(b, n, levels));
     if (need > kScratchBytes)
         return set_err(ctx, VW_E_WORKSPACE,
