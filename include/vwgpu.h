@@ -126,9 +126,17 @@ int32_t vw_device_count(void);
  * "inv_tile" (value = chunks per tile * 100 + halo chunks, e.g. 401; 0 = planner's choice), "fwd_chunks"
  * (tiles per run of the streaming forward), "stream_wgs" (workgroups wanted per streaming launch),
  * "sdry_chunks" (run length of the long-context kernels), "no_sdry", "no_unroll", "no_reg_select",
- * "no_std_chains", "no_row_denoise" (0/1), "nt_stores" (-1 by launch size, 0, 1), "reset" (all defaults).
- * Unknown names return VW_E_UNSUPPORTED. */
+ * "no_std_chains", "no_wide_inv", "no_vec2" (0/1), "no_ring" / "no_blk" (0/1: inverse tile kernel without the
+ * LDS-DMA band ring / without register-blocked windows), "no_row_denoise" / "no_band_regs" (0/1: short-row
+ * denoise through the three-launch path / with its bands in LDS instead of registers), "inv_vm" (0, 1, 2: one-
+ * sample, 8-byte-aligned pair, 16-byte pair accesses of the long-context inverse), "nt_stores" (-1 by launch
+ * size, 0, 1), "reset" (all defaults).  Unknown names return VW_E_UNSUPPORTED. */
 int32_t vw_set_plan_option(vw_ctx *ctx, const char *name, int64_t value);
+/* The kernels that the context's last forward and last inverse call enqueued, as text
+ * ("forward: k_fwd_stream[1-6]; inverse: k_inv_ring[1-6]": kernel family and the levels each launch covers; a
+ * single-launch denoise names its kernel on both sides).  For benchmarks and profiles that must name the kernel
+ * they measured; no counterpart in the reference.  Valid until the next call on the context. */
+const char *vw_last_plan(vw_ctx *ctx);
 
 /* Page-locked host memory for the HOST-pointer entry points.  They accept any host memory, but copies to and
  * from pageable memory go through the runtime's bounce buffers at a fraction of the PCIe rate; buffers obtained
@@ -247,7 +255,9 @@ size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
  * GPU, held from library load until the process ends.  The call makes no hipMalloc/hipFree and no other
  * allocating call.  Limit: vw_swt_denoise_workspace_bytes(b, n, levels) rounded up to 256 (plus b*n*8 for the
  * rare multi-pass plans) must not exceed VW_NOALLOC_SCRATCH_BYTES, else VW_E_WORKSPACE and nothing is
- * enqueued; the 8192 x 480, J = 4 streaming block needs 157,352,192 bytes.  Every call on one GPU uses that
+ * enqueued; 1000 rows of 4096 samples at J = 4 need 163,848,192 bytes and fit, 1024 such rows do not.  (Rows
+ * that the single-launch short-row kernels take -- up to 2048 samples with 2-, 4- or 8-tap filters, such as the
+ * 8192 x 480, J = 4 streaming block -- never touch the array and are not limited by it.)  Every call on one GPU uses that
  * GPU's one array (whatever the context or stream) and leaves its last contents there: calls that overlap in
  * time on one GPU race and must be ordered by the caller (one stream, or events); nothing in the array needs
  * clearing between calls, every byte a call reads was written by that call. */

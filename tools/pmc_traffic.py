@@ -15,7 +15,7 @@ out = sys.argv[6] if len(sys.argv) > 6 else os.path.join(os.path.dirname(__file_
 acc = defaultdict(lambda: [0.0, set()])
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(k_fwd_stream|k_fwd_fused|k_inv_fused)", r["Kernel_Name"])
+        m = re.search(r"(k_fwd_stream|k_fwd_fused|k_fwd_sdry|k_inv_fused|k_inv_blk|k_inv_ring|k_inv_sdry)", r["Kernel_Name"])
         if not m:
             continue
         a = acc[(m.group(1), r["Counter_Name"])]

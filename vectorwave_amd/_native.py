@@ -57,6 +57,7 @@ SIGNATURES = {
     "vw_performance_info": (C.c_char_p, [_vp]),
     "vw_synchronize": (C.c_int32, [_vp]),
     "vw_set_plan_option": (C.c_int32, [_vp, C.c_char_p, C.c_int64]),
+    "vw_last_plan": (C.c_char_p, [_vp]),
     "vw_device_count": (C.c_int32, []),
     "vw_max_levels": (C.c_int32, [C.c_int64, C.c_int32]),
     "vw_modwt_forward_batch": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _dp, C.c_int32, _dp, C.c_int32,
@@ -229,6 +230,10 @@ class Context:
 
     def performance_info(self) -> str:
         return self.lib.vw_performance_info(self.handle).decode()
+
+    def last_plan(self):
+        """vw_last_plan: the kernels the last forward and the last inverse call enqueued."""
+        return self.lib.vw_last_plan(self.handle).decode()
 
     def set_plan_option(self, name: str, value: int) -> None:
         """vw_set_plan_option: choose among equivalent launch plans (tests and tuning); 'reset' restores defaults."""

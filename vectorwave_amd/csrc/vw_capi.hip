@@ -61,6 +61,9 @@ struct vw_ctx {
     hipStream_t stream = nullptr;
     char err[512] = {0};
     char info[512] = {0};
+    char plan_fwd[96] = {0};             // kernels the last forward / inverse call enqueued (vw_last_plan)
+    char plan_inv[96] = {0};
+    char plan_txt[224] = {0};
     std::recursive_mutex mu;  // serialises use of the context-owned buffers below
     DevBuf ws;          // ping-pong plane [B][N] for multi-group / generic plans
     DevBuf stage_in;    // host-pointer entry points: device copy of the input
@@ -287,6 +290,21 @@ extern "C" int32_t vw_destroy(vw_ctx* ctx) {
 
 extern "C" const char* vw_last_error(const vw_ctx* ctx) { return ctx != nullptr ? ctx->err : "null context"; }
 extern "C" const char* vw_performance_info(const vw_ctx* ctx) { return ctx != nullptr ? ctx->info : "null context"; }
+
+// appends "name[lev0-lev1]" to one of the context's plan notes
+static void plan_note(char (&dst)[96], const char* name, int lev0, int lev1) {
+    const size_t used = strlen(dst);
+    if (used + 1 >= sizeof(dst)) return;
+    snprintf(dst + used, sizeof(dst) - used, "%s%s[%d-%d]", used ? "+" : "", name, lev0, lev1);
+}
+
+extern "C" const char* vw_last_plan(vw_ctx* ctx) {
+    if (ctx == nullptr) return "null context";
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    snprintf(ctx->plan_txt, sizeof(ctx->plan_txt), "forward: %s; inverse: %s", ctx->plan_fwd[0] ? ctx->plan_fwd : "-",
+             ctx->plan_inv[0] ? ctx->plan_inv : "-");
+    return ctx->plan_txt;
+}
 
 extern "C" int32_t vw_synchronize(vw_ctx* ctx) {
     if (ctx == nullptr) return VW_E_NULL;
@@ -658,8 +676,11 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
     const double* in = x;
     int64_t in_stride = n;
     bool first = true;
+    ctx->plan_fwd[0] = 0;
     for (int i = 0; i < nsteps; ++i) {
         const Step& st = steps[i];
+        plan_note(ctx->plan_fwd, st.sdry != 0 ? "k_fwd_sdry" : st.fused ? (st.cfg.hpt == 1 ? "k_fwd_stream" : "k_fwd_fused") : "k_level_fwd",
+                  st.lev0, st.lev1);
         // ping-pong so that the last step lands in the a_J band
         const bool to_slot = ((nsteps - 1 - i) % 2) == 0;
         double* vout = to_slot ? aslot : wsp;
@@ -942,6 +963,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
     int64_t rin_stride = rowc;
     bool use_rin = ((band_mask >> levels) & 1u) != 0;
     bool first = true;
+    ctx->plan_inv[0] = 0;
     for (int i = 0; i < nsteps; ++i) {
         const Step& st = steps[i];
         const bool to_out = ((nsteps - 1 - i) % 2) == 0;
@@ -988,6 +1010,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            plan_note(ctx->plan_inv, "k_inv_sdry", st.lev0, st.lev1);
             hipError_t e = launch_inv_sdry(a, st.sdry, boundary, ctx->opt.inv_vm >= 0 ? (ctx->opt.inv_vm == 1 && !vec2 ? 2 : ctx->opt.inv_vm) : (vec2 ? 1 : 2), (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(e));
         } else if (st.fused) {
@@ -1040,6 +1063,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
             const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1);
             const bool ring = blk && vec2 && n >= 2560 && !ctx->opt.no_ring && ctx->lds_limit >= 81920;
+            plan_note(ctx->plan_inv, ring ? "k_inv_ring" : blk ? "k_inv_blk" : "k_inv_fused", st.lev0, st.lev1);
             hipError_t er = ring  ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                             : blk ? launch_inv_blk(a, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                                   : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
@@ -1047,6 +1071,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
         } else {
             if (first && first_bad_cell != nullptr)
                 hipLaunchKernelGGL(k_first_non_finite, dim3(1024), dim3(kThreads), 0, stream, coeffs, b * rowc, first_bad_cell);
+            plan_note(ctx->plan_inv, "k_level_inv", st.lev0, st.lev1);
             LevelArgs a;
             memset(&a, 0, sizeof(a));
             const int j = st.lev0;
@@ -1410,6 +1435,9 @@ static int row_denoise_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t 
     scale_taps(gr, lh, a.rec.hi);
     // rows of up to 512 samples at up to four levels keep their detail bands in registers (one band buffer in LDS)
     const bool regs = n <= 512 && levels <= 4 && !ctx->opt.no_band_regs;
+    ctx->plan_fwd[0] = ctx->plan_inv[0] = 0;
+    plan_note(ctx->plan_fwd, regs ? "k_swt_denoise_rowreg" : "k_swt_denoise_row", 1, levels);
+    plan_note(ctx->plan_inv, regs ? "k_swt_denoise_rowreg" : "k_swt_denoise_row", 1, levels);
     const int64_t np = (n + 1) & ~static_cast<int64_t>(1);
     const int64_t hm = ((((static_cast<int64_t>(lh) - 1) << (levels - 1)) + 1) & ~static_cast<int64_t>(1)) + 2;
     const size_t lds = regs ? static_cast<size_t>(hm + np + hm + np + hm) * 8 : row_denoise_lds(n, levels, lh);
