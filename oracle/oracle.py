@@ -291,6 +291,21 @@ class StreamingTransformState:
         assert nb <= cap
         return out[:nb].copy()
 
+    def process_checked(self, data):
+        """process() with the reference's failure rule: returns (blocks emitted before the failure, index of the sample
+        whose window held a non-finite value or -1)."""
+        d = _f64(data)
+        hop = self.buffer_size - (self.h.size - 1)
+        cap = d.size // max(hop, 1) + 2
+        out = np.empty((cap, 2, self.buffer_size))
+        failed = C.c_int64(-1)
+        f = lib().vwo_stream_xform_process_checked
+        f.restype = C.c_int64
+        nb = f(self.handle, _p(d), C.c_int64(d.size), _p(self.h), C.c_int(self.h.size), _p(self.g), C.c_int(self.g.size),
+               C.c_int(self.boundary), _p(out), C.c_int64(cap), C.byref(failed))
+        assert nb <= cap
+        return out[:nb].copy(), int(failed.value)
+
     def flush(self):
         out = np.empty((1, 2, self.buffer_size))
         nb = lib().vwo_stream_xform_flush(self.handle, _p(self.h), C.c_int(self.h.size), _p(self.g), C.c_int(self.g.size),

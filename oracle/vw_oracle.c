@@ -855,6 +855,44 @@ int64_t vwo_stream_xform_process(vwo_stream_xform *s, const double *data, int64_
     return blocks;
 }
 
+/* The same walk with the reference's failure rule: MODWTTransform.forward validates its window
+ * (modwt/MODWTTransform.java:353-357), so the first window that holds a NaN or an infinity throws out of
+ * processBuffer (:194) before the consumed samples are subtracted (:226) and before the sample is counted
+ * (:179); the rest of `data` is never fed.  *failed_at receives the index of the sample whose window failed
+ * (-1 if none); the state is left as the reference leaves it (sample stored, count not reduced). */
+int64_t vwo_stream_xform_process_checked(vwo_stream_xform *s, const double *data, int64_t len, const double *h,
+                                         int lh, const double *g, int lg, int boundary, double *out,
+                                         int64_t max_blocks, int64_t *failed_at) {
+    const int64_t bsz = s->buffer_size;
+    int64_t blocks = 0;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)bsz);
+    *failed_at = -1;
+    for (int64_t t = 0; t < len; t++) {
+        s->ring[s->write_pos] = data[t];
+        s->write_pos = (s->write_pos + 1) % s->ring_len;
+        s->in_buffer++;
+        if (s->in_buffer >= bsz) {
+            int64_t read_pos = (s->write_pos - bsz + s->ring_len) % s->ring_len;
+            int finite = 1;
+            for (int64_t i = 0; i < bsz; i++) {
+                buf[i] = s->ring[(read_pos + i) % s->ring_len];
+                if (!isfinite(buf[i])) finite = 0;
+            }
+            if (!finite) {
+                *failed_at = t;
+                break;
+            }
+            if (blocks < max_blocks)
+                vwo_modwt_forward(buf, bsz, h, lh, g, lg, boundary, out + (blocks * 2 + 1) * bsz,
+                                  out + (blocks * 2) * bsz);
+            blocks++;
+            s->in_buffer -= bsz - s->overlap;
+        }
+    }
+    free(buf);
+    return blocks;
+}
+
 /* :205-231 (flush; close does the same, :255-280): the unconsumed samples, zero-padded to bufferSize,
  * make one last block; returns 1 if a block was written to out[2][bufferSize], else 0 */
 int vwo_stream_xform_flush(vwo_stream_xform *s, const double *h, int lh, const double *g, int lg,

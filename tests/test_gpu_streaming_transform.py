@@ -163,3 +163,42 @@ def test_multilevel_streaming_lockstep_and_errors(ctx):
     t = MODWTStreamingTransform.createMultiLevel("db4", BoundaryMode.PERIODIC, 16, 5, ctx=ctx)
     with pytest.raises(InvalidArgumentException):  # five levels do not fit a 16-sample block
         t.process(np.zeros(16))
+
+
+@pytest.mark.parametrize("wn,bsz,bad_at", [("db4", 64, [200]), ("haar", 16, [15]), ("db4", 32, [0]), ("sym8", 100, [250, 251]),
+                                           ("db2", 16, [37, 90])])
+def test_non_finite_window_fails_where_the_reference_fails(ctx, wn, bsz, bad_at):
+    """A window with a NaN or an infinity: the blocks before it are published, the call raises, and the buffer is left
+    as the reference leaves it (sample stored, nothing consumed), so that what the caller feeds next produces the
+    reference's blocks again.  Checked against the oracle's walk of the reference's sample loop."""
+    w = get_wavelet(wn)
+    rng = np.random.default_rng(bsz)
+    data = rng.standard_normal(9 * bsz + 7)
+    for k, b in enumerate(bad_at):
+        data[b] = np.nan if k % 2 == 0 else -np.inf
+    ref = o.StreamingTransformState(w, bsz, P)
+    sink = _Collector()
+    t = MODWTStreamingTransform.create(w, BoundaryMode.PERIODIC, bsz, ctx=ctx)
+    t.subscribe(sink)
+    want = []
+    pos, failures = 0, 0
+    chunks = [3 * bsz + 1, 5, bsz, 1, 4 * bsz]
+    k = 0
+    while pos < data.size:
+        piece = data[pos:pos + chunks[k % len(chunks)]]
+        k += 1
+        blocks, failed = ref.process_checked(piece)
+        want += list(blocks)
+        if failed < 0:
+            t.process(piece)
+            pos += piece.size
+        else:
+            failures += 1
+            with pytest.raises(InvalidSignalException):
+                t.process(piece)
+            pos += failed + 1
+        assert len(sink.items) == len(want)
+        assert t.getBufferLevel() == ref.level()
+    assert failures >= len(bad_at)
+    if want:
+        assert_bits_equal(sink.blocks(), np.array(want), "%s bufferSize=%d" % (wn, bsz))

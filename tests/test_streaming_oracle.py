@@ -256,3 +256,78 @@ def test_multilevel_streaming_blocks(wn, bsz, levels):
     assert got.shape[0] == 3
     # more levels than the block length allows: the reference's decompose throws
     assert o.stream_multilevel(data[:40], get_wavelet("db4"), 16, 5)[0] != 0
+
+
+# ---- the host-side mirror's buffering (vectorwave_amd/api.py), with the transform stubbed: no GPU -------------------
+
+def _py_stream_checked(state, data, buffer_size, overlap, multilevel=False):
+    """The reference's sample loop with forward()'s validation (MODWTStreamingTransformImpl.java:168-227,
+    MultiLevelMODWTStreamingTransform.java:124-167): state = [history list, samplesInBuffer, samples counted].
+    Returns (windows emitted, index of the failing sample or -1)."""
+    hist, level, counted = state
+    windows = []
+    for t, s in enumerate(data):
+        hist.append(s)
+        level += 1
+        if level >= buffer_size:
+            w = hist[-buffer_size:]
+            if not np.isfinite(w).all():
+                state[:] = [hist, level, counted]
+                return windows, t
+            windows.append(list(w))
+            level = 0 if multilevel else level - (buffer_size - overlap)
+        counted += 1
+    state[:] = [hist, level, counted]
+    return windows, -1
+
+
+class _StubbedTransform:
+    """Mixin: windows go to a list instead of the GPU; a non-finite window raises like the validating forward."""
+
+    def _transform_windows(self, windows):
+        from vectorwave_amd.api import InvalidSignalException
+        for k in range(windows.shape[1]):
+            w = np.array(windows[0, k])
+            if not np.isfinite(w).all():
+                raise InvalidSignalException("non-finite", "VAL_003")
+            self.seen_windows.append(w.tolist())
+
+
+@pytest.mark.parametrize("multilevel", [False, True])
+@pytest.mark.parametrize("bsz,bad_at", [(16, [40]), (16, [15]), (16, [0]), (8, [8, 9]), (32, [100, 164]), (16, [])])
+def test_mirror_buffering_follows_the_reference_through_failures(bsz, bad_at, multilevel):
+    from vectorwave_amd import api
+
+    base = api.MultiLevelMODWTStreamingTransform if multilevel else api.MODWTStreamingTransform
+    cls = type("Stubbed", (_StubbedTransform, base), {})
+    t = cls.__new__(cls)
+    if multilevel:
+        base.__init__(t, "db2", api.BoundaryMode.PERIODIC, bsz, 2, 1, ctx=object())
+    else:
+        base.__init__(t, "db2", api.BoundaryMode.PERIODIC, bsz, 1, ctx=object())
+    t.seen_windows = []
+    overlap = 0 if multilevel else 3
+    rng = np.random.default_rng(bsz + len(bad_at))
+    data = rng.standard_normal(12 * bsz + 5)
+    for b in bad_at:
+        data[b] = np.nan if b % 2 == 0 else np.inf
+    state = [[], 0, 0]
+    want_windows = []
+    pos, chunk = 0, 0
+    chunks = [5, bsz, 3 * bsz + 1, 1, 2, 7 * bsz]
+    while pos < data.size:
+        size = chunks[chunk % len(chunks)]
+        chunk += 1
+        piece = data[pos:pos + size]
+        w, failed = _py_stream_checked(state, piece.tolist(), bsz, overlap, multilevel)
+        want_windows += w
+        if failed < 0:
+            t.process(piece)
+            pos += piece.size
+        else:
+            with pytest.raises(api.InvalidSignalException):
+                t.process(piece)
+            pos += failed + 1  # the caller carries on after the sample that failed
+        assert t.seen_windows == want_windows
+        assert t.getBufferLevel() == state[1]
+        assert t.getStatistics().getSamplesProcessed() == state[2]

@@ -125,29 +125,33 @@ def biorthogonal():
     return res
 
 
-def main():
-    if not os.path.isdir(REF):
-        sys.exit("reference tree not present; the committed JSON is authoritative")
+def build_tables():
+    """The JSON document, extracted from the reference tree in memory."""
     ortho = {"haar": [1.0 / math.sqrt(2), 1.0 / math.sqrt(2)]}
     ortho.update(daubechies())
     ortho.update(simple_family(f"{REF}/api/Symlet.java", "Symlet", "sym"))
     ortho.update(simple_family(f"{REF}/api/Coiflet.java", "Coiflet", "coif"))
     ortho.update(dmey())
     bior = biorthogonal()
-
-    doc = {
+    return {
         "_comment": "Low-pass tap tables as C99 hex floats; generated by tools/extract_wavelet_tables.py",
         "orthogonal": {k: [x.hex() for x in v] for k, v in ortho.items()},
         "biorthogonal": {k: {"dec_lo": [x.hex() for x in v[0]], "rec_lo": [x.hex() for x in v[1]]}
                          for k, v in bior.items()},
     }
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; the committed JSON is authoritative")
+    doc = build_tables()
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1)
-    print("orthogonal:", len(ortho), "biorthogonal:", len(bior))
-    for k, v in ortho.items():
+    print("orthogonal:", len(doc["orthogonal"]), "biorthogonal:", len(doc["biorthogonal"]))
+    for k, v in doc["orthogonal"].items():
         print("  %-7s L=%d" % (k, len(v)))
-    for k, v in bior.items():
-        print("  %-8s Ldec=%d Lrec=%d" % (k, len(v[0]), len(v[1])))
+    for k, v in doc["biorthogonal"].items():
+        print("  %-8s Ldec=%d Lrec=%d" % (k, len(v["dec_lo"]), len(v["rec_lo"])))
 
 
 if __name__ == "__main__":

@@ -1097,7 +1097,8 @@ class MODWTStreamingTransform:
         self.bufferSize = int(bufferSize)
         self.streams = int(streams)
         self._transform = MODWTTransform(self.wavelet, self.boundaryMode, ctx)
-        self._pending = np.empty((self.streams, 0))  # the unconsumed samples (samplesInBuffer of them)
+        self._history = np.empty((self.streams, 0))  # the last samples seen (at most bufferSize): the circular buffer
+        self._samples_in_buffer = 0                  # samplesInBuffer of the reference
         self._closed = False
         self._subscribers = []
         self._statistics = StreamingStatistics()
@@ -1149,29 +1150,66 @@ class MODWTStreamingTransform:
             raise InvalidStateException("Transform is closed")
         self._feed(np.asarray(sample, dtype=np.float64).reshape(self.streams, 1))
 
+    def _after_window(self, count):
+        """samplesInBuffer after a window went out (MODWTStreamingTransformImpl.java:216-226)"""
+        return count - (self.bufferSize - self.overlapSize)
+
     def _feed(self, d):
-        hop = self.bufferSize - self.overlapSize
-        cat = np.concatenate([self._pending, d], axis=1)
-        total = cat.shape[1]
-        k = (total - self.bufferSize) // hop + 1 if total >= self.bufferSize else 0
-        if k > 0:
-            windows = np.lib.stride_tricks.sliding_window_view(cat, self.bufferSize, axis=1)[:, : (k - 1) * hop + 1 : hop]
-            try:
-                self._transform_windows(windows)
-            finally:
-                # the reference has consumed the samples of every window it reached, valid or not
-                self._pending = cat[:, k * hop:].copy()
-                self._statistics._samples += d.shape[1]
+        """The reference's sample loop (:154-180) for a whole array: a window goes out whenever samplesInBuffer reaches
+        bufferSize, and holds the last bufferSize samples.  All windows that the array completes are transformed as
+        one batch.  A window that holds a NaN or an infinity fails like MODWTTransform.forward fails in the
+        reference (:194): the windows before it are published, the sample that completed it is stored but neither
+        counted nor consumed, the rest of the array is dropped, and the exception propagates."""
+        m = d.shape[1]
+        seen = self._history.shape[1]
+        hist = np.concatenate([self._history, d], axis=1)
+        ends, counts = [], []  # data index of the sample that completes each window; samplesInBuffer at that moment
+        count, i = self._samples_in_buffer, -1
+        while True:
+            need = max(1, self.bufferSize - count)
+            if i + need >= m:
+                break
+            i += need
+            ends.append(i)
+            counts.append(count + need)
+            count = self._after_window(count + need)
+        bad = None
+        if ends:
+            nonfinite = np.concatenate([[0], np.cumsum(~np.isfinite(hist).all(axis=0))])
+            for k, e in enumerate(ends):
+                if nonfinite[seen + e + 1] - nonfinite[seen + e + 1 - self.bufferSize] > 0:
+                    bad = k
+                    break
+        good = ends if bad is None else ends[:bad]
+        starts = np.asarray(good, dtype=np.int64) + (seen + 1 - self.bufferSize)
+        all_windows = np.lib.stride_tricks.sliding_window_view(hist, self.bufferSize, axis=1) if ends else None
+        if bad is None:
+            self._samples_in_buffer = count + (m - 1 - i)
+            self._history = hist[:, -self.bufferSize:].copy()
+            self._statistics._samples += m
+            if good:
+                self._transform_windows(all_windows[:, starts])
             return
-        self._pending = cat
-        self._statistics._samples += d.shape[1]
+        failed_at = ends[bad]
+        self._samples_in_buffer = counts[bad]
+        self._history = hist[:, : seen + failed_at + 1][:, -self.bufferSize:].copy()
+        self._statistics._samples += failed_at
+        if good:
+            self._transform_windows(all_windows[:, starts])
+        # the failing window goes through the same validating call and raises what forward() raises
+        self._transform_windows(all_windows[:, [seen + failed_at + 1 - self.bufferSize]])
+        raise InvalidSignalException("window contains non-finite values", "VAL_003")
 
     def _drain(self):
-        level = self._pending.shape[1]
+        level = self._samples_in_buffer
         if level > 0:
+            if level > self.bufferSize:
+                # only after a failed window: the reference's copy loop runs past finalBuffer (:240-242)
+                raise IndexError("Index %d out of bounds for length %d" % (self.bufferSize, self.bufferSize))
             final = np.zeros((self.streams, 1, self.bufferSize))
-            final[:, 0, :level] = self._pending
-            self._pending = np.empty((self.streams, 0))
+            final[:, 0, :level] = self._history[:, self._history.shape[1] - level:]
+            self._history = np.empty((self.streams, 0))
+            self._samples_in_buffer = 0
             self._transform_windows(final)
 
     def flush(self):
@@ -1187,11 +1225,12 @@ class MODWTStreamingTransform:
         """:238-250"""
         if self._closed:
             raise InvalidStateException("Transform is closed")
-        self._pending = np.empty((self.streams, 0))
+        self._history = np.empty((self.streams, 0))
+        self._samples_in_buffer = 0
         self._statistics.reset()
 
     def getBufferLevel(self):
-        return int(self._pending.shape[1])
+        return int(self._samples_in_buffer)
 
     def isClosed(self):
         return self._closed
@@ -1239,7 +1278,8 @@ class MultiLevelMODWTStreamingTransform(MODWTStreamingTransform):
         self.filterLength = len(self.wavelet.dec_lo)
         self.overlapSize = 0  # blocks do not overlap here (:161 resets the sample count to zero)
         self._ml = MultiLevelMODWTTransform(self.wavelet, self.boundaryMode, ctx)
-        self._pending = np.empty((self.streams, 0))
+        self._history = np.empty((self.streams, 0))
+        self._samples_in_buffer = 0
         self._closed = False
         self._subscribers = []
         self._statistics = StreamingStatistics()
@@ -1265,6 +1305,10 @@ class MultiLevelMODWTStreamingTransform(MODWTStreamingTransform):
         coeffs = self._ml.decompose_block(rows, self.levels, True).reshape(self.streams, k, self.levels + 1, self.bufferSize)
         self._submit(coeffs)
         self._statistics._record_blocks(k, time.perf_counter_ns() - t0)
+
+    def _after_window(self, count):
+        """:166: the first-level counter restarts at zero after every block"""
+        return 0
 
     def flush(self):
         """:166-196 (no closed check in the reference)"""
