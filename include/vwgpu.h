@@ -127,7 +127,9 @@ int32_t vw_device_count(void);
  * (tiles per run of the streaming forward), "stream_wgs" (workgroups wanted per streaming launch),
  * "sdry_chunks" (run length of the long-context kernels), "no_sdry", "no_unroll", "no_reg_select",
  * "no_std_chains", "no_wide_inv", "no_vec2" (0/1), "no_ring" / "no_blk" (0/1: inverse tile kernel without the
- * LDS-DMA band ring / without register-blocked windows), "no_row_denoise" / "no_band_regs" (0/1: short-row
+ * LDS-DMA band ring / without register-blocked windows), "carry_chunks" (>= 2: the ring kernel over runs of that
+ * many tiles with the right context carried from tile to tile; 0 = one tile per workgroup, the default),
+ * "no_row_denoise" / "no_band_regs" (0/1: short-row
  * denoise through the three-launch path / with its bands in LDS instead of registers), "inv_vm" (0, 1, 2: one-
  * sample, 8-byte-aligned pair, 16-byte pair accesses of the long-context inverse), "nt_stores" (-1 by launch
  * size, 0, 1), "reset" (all defaults).  Unknown names return VW_E_UNSUPPORTED. */

@@ -295,13 +295,14 @@ def test_status_codes(ctx):
 
 
 @pytest.mark.parametrize("mode", [P, Z])
-@pytest.mark.parametrize("variant", ["ring", "blk", "fused"])
+@pytest.mark.parametrize("variant", ["ring", "carry2", "carry3", "carry8", "blk", "fused"])
 @pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("db4", 2560, 5, 2), ("db4", 6002, 6, 2), ("haar", 8192, 8, 2),
                                       ("haar", 20480, 7, 1), ("db2", 12290, 7, 2), ("sym4", 4096, 4, 3), ("db4", 2048, 1, 2),
                                       ("db4", 30000, 2, 1), ("bior1.3", 9000, 6, 2)])
 def test_inverse_tile_kernel_families_bit_exact(ctx, plan, wn, n, j, b, variant, mode):
-    """The three inverse tile kernels behind one plan -- LDS-DMA ring (default on 16-byte-aligned rows of 2560+ samples),
-    register-blocked with register landing, and the unblocked k_inv_fused -- must each reproduce the oracle: plain
+    """The inverse tile kernels behind one plan -- the LDS-DMA ring (default on 16-byte-aligned rows of 2560+ samples), the
+    ring over runs of 2, 3 and 8 tiles with carried right contexts (opt-in), register-blocked with register landing, and
+    the unblocked k_inv_fused -- must each reproduce the oracle: plain
     inverse, inverse with the finite check, thresholding inverse (denoise) and band-masked inverse, on interior
     tiles, on the last tile of a row (wrap / zeros) and on rows that are not a whole number of tiles."""
     import ctypes as C
@@ -309,6 +310,8 @@ def test_inverse_tile_kernel_families_bit_exact(ctx, plan, wn, n, j, b, variant,
         plan("no_ring", 1)
     elif variant == "fused":
         plan("no_blk", 1)
+    elif variant.startswith("carry"):
+        plan("carry_chunks", int(variant[5:]))
     w = get_wavelet(wn)
     x = signals(b, n, seed=n + j)
     st, coeffs = o.decompose_batch(x, w, j, mode)

@@ -46,6 +46,8 @@ struct PlanOptions {
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
     int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
     int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
+    int carry_chunks = 0;                // >= 2: the ring kernel over runs of that many tiles with carried right contexts
+                                         // (k_inv_carry); measured 5-7 % slower than one tile per workgroup, so off by default
     int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
     int inv_vm = 0;                      // global access mode of the long-context inverse: 0 one sample per access
                                          // (measured 6 % faster than pairs, aligned or not), 1 / 2 pairs, -1 by alignment
@@ -193,6 +195,8 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_blk = value != 0;
     } else if (strcmp(name, "no_ring") == 0) {
         o.no_ring = value != 0;
+    } else if (strcmp(name, "carry_chunks") == 0) {
+        o.carry_chunks = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_wide_inv") == 0) {
         o.no_wide_inv = value != 0;
     } else if (strcmp(name, "inv_vm") == 0) {
@@ -212,7 +216,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
+                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -362,7 +366,7 @@ static constexpr int kHaloMaxChunks = 10;  // largest HPT instantiated
 //   inverse, fused multiply-add: the loop is LDS-bound and 4096-sample tiles amortise the halo best
 static const TileCfg kFwdCfgs[] = {{2, 1, 256}, {4, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
 static const TileCfg kInvCfgs[] = {{4, 1, 256}, {2, 1, 256}, {8, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
-static const TileCfg kInvCfgsFma[] = {{8, 1, 256}, {4, 1, 256}, {2, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
+static const TileCfg kInvCfgsFma[] = {{4, 1, 256}, {8, 1, 256}, {2, 1, 256}, {1, 1, 256}, {4, 2, 256}, {8, 2, 256}, {8, 4, 256}, {8, 10, 256}};
 
 struct CfgList {
     const TileCfg* v;
@@ -1063,8 +1067,20 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
             const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1);
             const bool ring = blk && vec2 && n >= 2560 && !ctx->opt.no_ring && ctx->lds_limit >= 81920;
-            plan_note(ctx->plan_inv, ring ? "k_inv_ring" : blk ? "k_inv_blk" : "k_inv_fused", st.lev0, st.lev1);
-            hipError_t er = ring  ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
+            // opt-in: runs of tiles with carried right contexts
+            bool carry = ring && ctx->opt.carry_chunks >= 2 && a.ntiles > 1 && inv_carry_supported(a.lh, st.lev0, st.lev1);
+            int64_t nlaunch = nblocks;
+            if (carry) {
+                const int64_t tiles = a.ntiles;
+                const int64_t nch = ctx->opt.carry_chunks < tiles ? ctx->opt.carry_chunks : tiles;
+                a.tiles_per_row = static_cast<int32_t>(tiles);
+                a.nchunks = static_cast<int32_t>(nch);
+                a.ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
+                nlaunch = b * a.ntiles;
+            }
+            plan_note(ctx->plan_inv, carry ? "k_inv_carry" : ring ? "k_inv_ring" : blk ? "k_inv_blk" : "k_inv_fused", st.lev0, st.lev1);
+            hipError_t er = carry ? launch_inv_carry(a, boundary, (flags & VW_FLAG_FMA) != 0, nlaunch, stream)
+                            : ring ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                             : blk ? launch_inv_blk(a, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                                   : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
             if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));

@@ -1636,6 +1636,314 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_inv_carry: k_inv_ring over a run of tiles, with the right context carried from tile to tile
+// ---------------------------------------------------------------------------
+//
+// k_inv_ring pays for the right context of every tile twice: a fifth 512-sample chunk of every band is loaded and
+// the running reconstruction is recomputed on it level by level (a quarter more loads, LDS reads and arithmetic).
+// Here a workgroup walks a run of tiles of one row from right to left.  Only the first tile of the run is treated
+// as in k_inv_ring; for every later tile the right context of level j -- the first (L-1) 2^(j-1) samples of R_j
+// and of W_j of the tile just done, its "heads" -- is taken from LDS.  A buffer is used as
+//     pairs [0, 1024)     the tile
+//     pairs [1024, 1152)  right context (the heads of the previous tile; the first tile's loaded / recomputed halo)
+//     pairs [1152, 1280)  head storage
+// so the four buffers keep their 20 KiB.  Only the top level of a run's first tile needs more than 128 pairs of
+// context; it overruns the head storage of the R buffer and of its own band slot before anything is stored there,
+// and its own heads go to the other two buffers.  Heads are exchanged by the lanes that already hold the values:
+// the two waves whose LDS-DMA filled pairs 0..127 of a band (after their own wait for it), and the lanes that
+// write R_{j-1} back; the owner takes the old head out, stores the new one and puts the old one into the context
+// zone, so no extra barrier is needed.  Later tiles issue four LDS-DMA instructions per band and wave, the first
+// tile four or five (a wave skips the fifth when its block lies right of the needed zone, which also keeps the head
+// storage intact); the counted waits follow.
+constexpr int kCarryCtx = 128;                               // pairs of right context behind the tile
+constexpr int kCarrySpare = 4 * kThreads + kCarryCtx;        // first pair of a buffer's head storage
+
+struct CarryHeads {
+    unsigned order;  // buffer index (0 = R, 1..3 = band slots) of head-storage area q in byte q
+};
+// LDS byte offset of pair v of the head storage (four areas of 128 pairs)
+__device__ __forceinline__ int carry_head_addr(const CarryHeads& h, int v) {
+    const int buf = (h.order >> ((v >> 7) << 3)) & 0xff;
+    return buf * kRingBand + ((kCarrySpare + (v & 127)) << 4);
+}
+
+// One band of this tile into the buffer at `dst`; returns nothing, issues 4 instructions, or 5 on the first tile of a
+// run when the wave's block of the fifth chunk holds needed pairs.
+template <int MODE>
+__device__ __forceinline__ void carry_issue(const double* __restrict__ src, unsigned lds_base, int dst, int S, int pl, int64_t t0,
+                                            int64_t n, int wave, int lane, bool first, bool redge) {
+    const int pair0 = blk_slot_rt(64 * wave + lane, S);
+    const unsigned ldst = lds_base + dst + 1024 * wave;
+    const bool fifth = first && (4 * kThreads + 64 * wave < pl);
+    if (!redge) {
+        const double* tsrc = src + t0;  // wave-uniform
+        const unsigned off0 = static_cast<unsigned>(pair0) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_so(tsrc, off0 + 4096u * i, ldst + 4096u * i);
+        if (fifth) {
+            const int p4 = pair0 + 4 * kThreads;
+            glds16_so(tsrc, static_cast<unsigned>(p4 < pl ? p4 : pl - 1) << 4, ldst + 4096u * 4);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (i < 4 || fifth) {
+            int pair = pair0 + i * kThreads;
+            pair = pair < pl ? pair : pl - 1;
+            int64_t t = t0 + 2 * pair;
+            if (t >= n) t = (MODE == kPeriodic) ? t - n : n - 2;
+            glds16(src + t, ldst + 4096u * i);
+        }
+    }
+}
+
+// write-back of R_{j-1} in the layout of the level that reads it (log2 stride SR); the owners of its first hp pairs also
+// store them as the head for the next tile and put the previous tile's head (`oldh`, read out before the level's
+// arithmetic so that no LDS round trip sits between the two barriers) into the context zone
+template <int SR, int MODE>
+__device__ __forceinline__ void carry_writeback(char* lds, const double (&acc)[5][2], int P0, int sp, int ph_own, bool hwr, int64_t t0,
+                                                int64_t n, bool first, bool heads /*wave-uniform: this wave owns head pairs*/,
+                                                const CarryHeads& hb, int vhead, int hp, const double2 (&oldh)[4]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (k < 4 || hwr) {
+            const int pair = (k < 4) ? P0 + k * sp : ph_own;
+            double2 v = make_double2(acc[k][0], acc[k][1]);
+            if (MODE == kZeroPad) {
+                // samples right of the signal are zero at every level
+                const int64_t t = t0 + 2 * pair;
+                if (t >= n) v.x = 0.0;
+                if (t + 1 >= n) v.y = 0.0;
+            }
+            *reinterpret_cast<double2*>(lds + (blk_slot<SR>(pair) << 4)) = v;
+            if (heads && k < 4 && pair < hp) {
+                *reinterpret_cast<double2*>(lds + carry_head_addr(hb, vhead + pair)) = v;
+                if (!first) *reinterpret_cast<double2*>(lds + (blk_slot<SR>(4 * kThreads + pair) << 4)) = oldh[k];
+            }
+        }
+    }
+}
+
+template <int LT, int MODE, bool FMA, bool PLAIN>
+__global__ void __launch_bounds__(kThreads, 2) k_inv_carry(const InvArgs a) {
+    extern __shared__ double2 vw_smem[];
+    constexpr int PPT = 4, NP = 5;
+    constexpr int T = PPT * kChunk;
+    char* lds = reinterpret_cast<char*>(vw_smem);
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));  // LDS byte address of the R buffer
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    // a.ntiles: runs per row, counted from the right end of the row; a.nchunks: tiles per run
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t row = id / a.ntiles;
+    const int seg = static_cast<int>(id - row * a.ntiles);
+    const int hi_tile = a.tiles_per_row - 1 - seg * a.nchunks;
+    const int ntl = (hi_tile + 1 < a.nchunks) ? hi_tile + 1 : a.nchunks;
+    const int64_t n = a.n;
+    const double* __restrict__ wbase = a.win + row * a.w_row_stride;
+
+    double tl[LT], th[LT];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) {
+        tl[i] = a.taps.lo[i];
+        th[i] = a.taps.hi[i];
+    }
+    // head storage in the order: slot of band lev1 - 1, slot of band lev1 - 2, R buffer, slot of band lev1
+    CarryHeads hb;
+    hb.order = static_cast<unsigned>(1 + (a.lev1 + 2) % 3) | (static_cast<unsigned>(1 + (a.lev1 + 1) % 3) << 8) |
+               (static_cast<unsigned>(1 + a.lev1 % 3) << 24);
+    // R_j is valid on buffer positions [0, pend(j)) in the first tile of a run: the tile plus the right context that
+    // levels j .. lev0 still need (the host's InvArgs::pend, recomputed here so that no scalar load sits in the level loop)
+    const int lev0m = 1 << (a.lev0 - 1);
+    auto pend = [&](int j) {
+        if (j < a.lev0) return T;
+        const int e = (LT - 1) * ((1 << j) - lev0m);
+        const int pe = T + ((e + 1) & ~1);
+        return pe < 2 * kBlkPairs ? pe : 2 * kBlkPairs;
+    };
+
+    for (int ch = 0; ch < ntl; ++ch) {
+        const bool first = (ch == 0);
+        const int64_t t0 = static_cast<int64_t>(hi_tile - ch) * T;
+        // the first tile (with its halo) may reach beyond its row: loads wrap or clamp lane by lane, and a
+        // ZERO_PADDING tile needs zeros there even in the plain form; later tiles lie inside the row
+        const bool redge = first && (t0 + 2 * kBlkPairs > n);
+        const bool edge = (MODE == kZeroPad) && redge;
+        auto pairs_of = [&](int j) { return first ? (pend(j) >> 1) : 4 * kThreads; };
+        auto issued = [&](int j) { return j >= a.lev0 ? 4 + ((first && 4 * kThreads + 64 * wave < (pend(j) >> 1)) ? 1 : 0) : 0; };
+
+        // prologue: R_{lev1}, W_{lev1}, W_{lev1-1}
+        carry_issue<MODE>(a.rin + row * a.rin_stride, lds_base, 0, a.lev1 - 2, pairs_of(a.lev1), t0, n, wave, lane, first, redge);
+        carry_issue<MODE>(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, lds_base, (1 + a.lev1 % 3) * kRingBand, a.lev1 - 2,
+                          pairs_of(a.lev1), t0, n, wave, lane, first, redge);
+        if (a.lev1 - 1 >= a.lev0)
+            carry_issue<MODE>(wbase + static_cast<int64_t>(a.lev1 - 2) * a.w_band_stride, lds_base, (1 + (a.lev1 - 1) % 3) * kRingBand,
+                              a.lev1 - 3, pairs_of(a.lev1 - 1), t0, n, wave, lane, first, redge);
+
+        int vR = 0, vW = kCarryCtx;  // head storage of level j: R_j at pair vR, W_j at pair vW
+        for (int j = a.lev1; j >= a.lev0; --j) {
+            const int S = j - 2;
+            const int hpj = (((LT - 1) << (j - 1)) + 1) >> 1;  // pairs of right context of level j
+            // two levels ahead; its slot was last read at level j+1, whose readers all passed that level's second barrier
+            if (j - 2 >= a.lev0)
+                carry_issue<MODE>(wbase + static_cast<int64_t>(j - 3) * a.w_band_stride, lds_base, (1 + (j - 2) % 3) * kRingBand, j - 4,
+                                  pairs_of(j - 2), t0, n, wave, lane, first, redge);
+            // the previous tile's heads are read out while the band is still on its way: those of W_j (and of R_j at the top
+            // level) by the lanes of the two waves whose first block holds pairs 0..127, that of R_{j-1} by the lanes that will
+            // write those pairs back (the ownership of a level is the same in every tile)
+            const int hi = 64 * wave + lane;
+            const bool hx = (wave < 2) && (hi < hpj);
+            const int vRn = (j == a.lev1) ? 2 * kCarryCtx : vW + hpj;  // head storage of the next level down
+            const int hpn = (j >= 2) ? ((((LT - 1) << (j - 2)) + 1) >> 1) : 0;
+            const int spj = (j >= 2) ? (1 << S) : 0;
+            const int P0j = (j >= 2) ? (((tid >> S) << (S + 2)) + (tid & (spj - 1))) : 0;
+            double2 oldw = make_double2(0.0, 0.0), oldr = make_double2(0.0, 0.0), oldn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) oldn[k] = make_double2(0.0, 0.0);
+            // (wave-uniform conditions and clamped addresses: no lane-dependent control flow around the reads)
+            if (!first) {
+                if (wave < 2) {
+                    const int hc = hx ? hi : 0;
+                    oldw = *reinterpret_cast<const double2*>(lds + carry_head_addr(hb, vW + hc));
+                    if (j == a.lev1) oldr = *reinterpret_cast<const double2*>(lds + carry_head_addr(hb, vR + hc));
+                }
+                if (wave == 0 && j > a.lev0) {  // pairs below 128 all belong to lanes of the first wave
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int pair = P0j + k * spj;
+                        oldn[k] = *reinterpret_cast<const double2*>(lds + carry_head_addr(hb, vRn + (pair < hpn ? pair : 0)));
+                    }
+                }
+            }
+            // everything older than the two youngest bands has landed: R (first pass) and W_j
+            if (!PLAIN) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                switch (issued(j - 1) + issued(j - 2)) {
+                    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                }
+            }
+            const int wofs = (1 + j % 3) * kRingBand;
+            if (!PLAIN || edge) {
+                // pass over the slots this wave has filled: W_j (and R on the first level)
+                const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+                const bool use_w = (a.band_mask >> (j - 1)) & 1u;
+                const bool use_r = (a.band_mask >> 31) & 1u;
+                const int pl = pairs_of(j);
+                const int nfill = issued(j);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if (i < nfill) {
+                        const int slot = 64 * (wave + 4 * i) + lane;
+                        const int pair = blk_slot_rt(slot, S);
+                        const int64_t t = t0 + 2 * pair;
+                        const bool inrow = (MODE == kPeriodic) || (t < n);
+                        double2* pw = reinterpret_cast<double2*>(lds + wofs + 16 * slot);
+                        double2 w = *pw;
+                        if (!use_w || !inrow || pair >= pl) w = make_double2(0.0, 0.0);
+                        if (a.thr_mode != 0) {
+                            w.x = apply_thr(w.x, thr, a.thr_mode);
+                            w.y = apply_thr(w.y, thr, a.thr_mode);
+                        }
+                        if (a.first_bad != nullptr && pair < kThreads * PPT && t < n) {
+                            const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
+                            if (!finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                            if (!finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                        }
+                        *pw = w;
+                        if (j == a.lev1) {
+                            double2* pr = reinterpret_cast<double2*>(lds + 16 * slot);
+                            double2 r = *pr;
+                            if (!use_r || !inrow || pair >= pl) r = make_double2(0.0, 0.0);
+                            if (a.first_bad != nullptr && a.check_rin && pair < kThreads * PPT && t < n) {
+                                const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
+                                if (!finite_f64(r.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
+                                if (!finite_f64(r.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                            }
+                            *pr = r;
+                        }
+                    }
+                }
+            }
+            // the previous tile's heads become this tile's right context
+            const int hown = blk_slot_rt(hi, S) << 4, hctx = blk_slot_rt(4 * kThreads + hi, S) << 4;
+            if (hx && !first) {
+                *reinterpret_cast<double2*>(lds + wofs + hctx) = oldw;
+                if (j == a.lev1) *reinterpret_cast<double2*>(lds + hctx) = oldr;
+            }
+            lds_barrier();  // every wave's part of W_j has landed, R_j and both contexts are written
+
+            // this tile's heads, requested ahead of the operand windows and stored behind the arithmetic
+            double2 neww = make_double2(0.0, 0.0), newr = make_double2(0.0, 0.0);
+            if (hx) {
+                neww = *reinterpret_cast<const double2*>(lds + wofs + hown);
+                if (j == a.lev1) newr = *reinterpret_cast<const double2*>(lds + hown);
+            }
+
+            const int pe = (first && j > a.lev0) ? pend(j - 1) : T;  // later tiles and the last level only need the tile
+            const bool hact = (T + 128 * wave) < pe;
+            const int ph_own = kThreads * PPT + tid;
+            const bool hwr = 2 * ph_own < pe;
+            const int ph = hwr ? ph_own : (pe >> 1) - 1;
+            double acc[NP][2];
+            int P0 = 0;
+            acc[4][0] = acc[4][1] = 0.0;
+#define VW_CARRY_LEVEL(SS, SLOT)                                                                        \
+    inv_blk_main<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, tid, S, tl, th, acc, P0);              \
+    if (hact) inv_blk_halo<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, ph, S, tl, th, acc);
+            switch (j) {
+                case 1: inv_blk_level1<LT, FMA, (1 + 1) * kRingBand, true>(lds, tid, tl, th, acc); break;
+                case 2: VW_CARRY_LEVEL(0, 2) break;
+                case 3: VW_CARRY_LEVEL(1, 0) break;
+                case 4: VW_CARRY_LEVEL(2, 1) break;
+                case 5: VW_CARRY_LEVEL(3, 2) break;
+                case 6: VW_CARRY_LEVEL(4, 0) break;
+                case 7: VW_CARRY_LEVEL(4, 1) break;
+                default: VW_CARRY_LEVEL(4, 2) break;  // level 8
+            }
+#undef VW_CARRY_LEVEL
+            const int sp = spj;
+            if (hx) {
+                *reinterpret_cast<double2*>(lds + carry_head_addr(hb, vW + hi)) = neww;
+                if (j == a.lev1) *reinterpret_cast<double2*>(lds + carry_head_addr(hb, vR + hi)) = newr;
+            }
+
+            if (j == a.lev0) {
+                double* __restrict__ orow = a.rout + row * a.rout_stride;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int pair = (j == 1) ? k * kThreads + tid : P0 + k * sp;
+                    const int64_t t = t0 + 2 * pair;
+                    if (t < a.n_store) gstore2(orow + t, make_double2(acc[k][0], acc[k][1]), a.nt_store);
+                }
+            } else {
+                lds_barrier();  // every lane has finished reading R_j / W_j
+                // R_{j-1} in the layout of level j-1 (j > lev0 >= 1: a blocked level wrote these accumulators)
+                switch (j) {
+                    case 2: carry_writeback<-1, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                    case 3: carry_writeback<0, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                    case 4: carry_writeback<1, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                    case 5: carry_writeback<2, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                    case 6: carry_writeback<3, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                    default: carry_writeback<4, MODE>(lds, acc, P0, sp, ph_own, hwr, t0, n, first, wave == 0, hb, vRn, hpn, oldn); break;
+                }
+                vR = vRn;
+                vW = vRn + hpn;
+            }
+        }
+        if (ch + 1 < ntl) lds_barrier();  // the last level's reads are done before the next tile's bands land
+    }
+}
+
 // streaming inverse for long contexts: mirror image of k_fwd_sdry
 // ---------------------------------------------------------------------------
 //

@@ -35,6 +35,10 @@ bool inv_blk_supported(int taps, int top_level);
 hipError_t launch_inv_blk(const InvArgs& a, int mode, bool vec2, bool fma, int64_t nblocks, hipStream_t stream);
 // the same with the bands fed by LDS-DMA (k_inv_ring): additionally needs 16-byte-aligned rows and n >= 2560
 hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
+// the ring kernel over runs of tiles with carried right contexts (k_inv_carry): a.ntiles runs per row of a.nchunks tiles,
+// a.tiles_per_row tiles in all; inv_carry_supported tells whether the heads of this filter / level group fit the storage
+bool inv_carry_supported(int taps, int lev0, int lev1);
+hipError_t launch_inv_carry(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 // vec2: global access mode (0 one sample per access, 1 aligned pairs, 2 pairs at 8-byte alignment)
 hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, int vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);

@@ -73,6 +73,40 @@ hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks
     return hipErrorInvalidValue;
 }
 
+// run form of the ring kernel (right contexts carried from tile to tile)
+template <int LT, int MODE>
+static hipError_t launch_inv_carry_pm(const InvArgs& a, bool fma, bool plain, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (plain) return fma ? launch_tile(k_inv_carry<LT, MODE, true, true>, a, nblocks, lds, stream)
+                          : launch_tile(k_inv_carry<LT, MODE, false, true>, a, nblocks, lds, stream);
+    return fma ? launch_tile(k_inv_carry<LT, MODE, true, false>, a, nblocks, lds, stream)
+               : launch_tile(k_inv_carry<LT, MODE, false, false>, a, nblocks, lds, stream);
+}
+// Head storage: the top level's two heads take one 128-pair area each, the heads of the levels below share the other
+// two areas; below the top level no band of a run's first tile may reach into the storage behind pair 1152.
+bool inv_carry_supported(int taps, int lev0, int lev1) {
+    if (!inv_blk_supported(taps, lev1) || lev0 < 1 || lev1 < lev0) return false;
+    auto hp = [&](int j) { return (((taps - 1) << (j - 1)) + 1) >> 1; };
+    if (hp(lev1) > kCarryCtx) return false;
+    int below = 0, ctx_below = 0;
+    for (int j = lev0; j < lev1; ++j) {
+        below += 2 * hp(j);
+        ctx_below += (taps - 1) << (j - 1);
+    }
+    return below <= 2 * kCarryCtx && ((ctx_below + 1) >> 1) <= kCarryCtx;
+}
+#define VW_INV_CARRY_CASE(LT)                                                                                 \
+    if (a.lh == LT)                                                                                           \
+        return mode == kPeriodic ? launch_inv_carry_pm<LT, kPeriodic>(a, fma, plain, nblocks, lds, stream)    \
+                                 : launch_inv_carry_pm<LT, kZeroPad>(a, fma, plain, nblocks, lds, stream);
+hipError_t launch_inv_carry(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
+    const size_t lds = 4 * static_cast<size_t>(kRingBand);
+    const bool plain = a.thr_mode == 0 && a.first_bad == nullptr && a.band_mask == 0xffffffffu;
+    VW_INV_CARRY_CASE(2)
+    VW_INV_CARRY_CASE(4)
+    VW_INV_CARRY_CASE(8)
+    return hipErrorInvalidValue;
+}
+
 // vm: global access mode of the kernel (0 one sample, 1 aligned pairs, 2 pairs at 8-byte alignment)
 template <int NT, int P, int HB, int MODE>
 static hipError_t launch_inv_sdry_pm(const InvArgs& a, int vm, bool fma, int64_t nblocks, size_t lds, hipStream_t stream) {
