@@ -295,6 +295,35 @@ def test_status_codes(ctx):
 
 
 @pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("variant", ["runs", "runs1", "runs2", "runs3"])
+@pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("db4", 2560, 5, 2), ("db4", 6002, 6, 2), ("haar", 8192, 8, 2),
+                                      ("haar", 20480, 7, 1), ("db2", 12290, 7, 2), ("sym4", 4096, 4, 3), ("db4", 2048, 1, 2),
+                                      ("db4", 30000, 2, 1), ("db4", 65536, 6, 1)])
+def test_forward_tile_kernel_families_bit_exact(ctx, plan, wn, n, j, b, variant, mode):
+    """The streaming forward over runs of the planner's length and of 1, 2 and 3 tiles must reproduce the oracle: coefficients
+    of every band, with and without the finite check, first tiles (wrap / zeros left of the row), carried histories and rows
+    that are not a whole number of tiles."""
+    if len(variant) > 4:
+        plan("fwd_chunks", int(variant[4:]))
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=n + 3 * j)
+    st, want = o.decompose_batch(x, w, j, mode)
+    assert st == 0
+    st, got, _ = gpu_forward(ctx, x, wn, j, mode)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "%s forward %s N=%d J=%d" % (variant, wn, n, j))
+    assert "k_fwd_stream" in ctx.last_plan()
+    st, got, bad = gpu_forward(ctx, x, wn, j, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == 0 and bad == -1
+    assert_bits_equal(got, want, "%s checked forward" % variant)
+    xb = x.copy()
+    bad_at = (b - 1) * n + (n * 2) // 3
+    xb.reshape(-1)[bad_at] = np.nan
+    st, _, bad = gpu_forward(ctx, xb, wn, j, mode, N.VW_FLAG_CHECK_FINITE)
+    assert st == N.VW_E_NONFINITE and bad == bad_at
+
+
+@pytest.mark.parametrize("mode", [P, Z])
 @pytest.mark.parametrize("variant", ["ring", "carry2", "carry3", "carry8", "blk", "fused"])
 @pytest.mark.parametrize("wn,n,j,b", [("db4", 16384, 6, 3), ("db4", 2560, 5, 2), ("db4", 6002, 6, 2), ("haar", 8192, 8, 2),
                                       ("haar", 20480, 7, 1), ("db2", 12290, 7, 2), ("sym4", 4096, 4, 3), ("db4", 2048, 1, 2),
