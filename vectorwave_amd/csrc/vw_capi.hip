@@ -1060,6 +1060,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                 for (int j = st.lev0; j < st.lev1; ++j) a.pend[j] = T;
             if (strstr(ctx->opt.ablate, "ringnomath")) a.ablate |= 1;
             if (strstr(ctx->opt.ablate, "ringnoload")) a.ablate |= 2;
+            if (strstr(ctx->opt.ablate, "ringonewg")) a.ablate |= 8;
 #endif
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout) &&
                               !ctx->opt.no_vec2;

@@ -65,7 +65,8 @@ static hipError_t launch_inv_ring_pm(const InvArgs& a, bool fma, bool plain, int
         return mode == kPeriodic ? launch_inv_ring_pm<LT, kPeriodic>(a, fma, plain, nblocks, lds, stream)     \
                                  : launch_inv_ring_pm<LT, kZeroPad>(a, fma, plain, nblocks, lds, stream);
 hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
-    const size_t lds = 4 * static_cast<size_t>(kRingBand);
+    size_t lds = 4 * static_cast<size_t>(kRingBand);
+    if (VW_ABLATED(a, 3)) lds += 24576;  // tuning build: one workgroup per CU instead of two
     const bool plain = a.thr_mode == 0 && a.first_bad == nullptr && a.band_mask == 0xffffffffu;
     VW_INV_RING_CASE(2)
     VW_INV_RING_CASE(4)
