@@ -63,3 +63,48 @@ def test_row_denoise_in_place_and_device_pointers(ctx):
     out, _ = dev_denoise(ctx, x_t, "db4", 4, P, -1.0, True, out=x_t)
     assert out.data_ptr() == x_t.data_ptr()
     assert_bits_equal(x_t.cpu().numpy(), want, "in place")
+
+
+N1_CASES = [  # wavelet, n, levels (0 = the single-level form), rows
+    ("db4", 480, 4, 9), ("db4", 480, 0, 5), ("db4", 481, 3, 3), ("db4", 64, 2, 4), ("db4", 1000, 5, 2), ("db4", 2048, 2, 2),
+    ("haar", 33, 3, 3), ("haar", 480, 4, 3), ("db2", 300, 0, 4), ("sym4", 512, 4, 2), ("db4", 40, 1, 3), ("haar", 64, 0, 2),
+]
+
+
+@pytest.mark.parametrize("variant", ["regs", "lds", "mat"])
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("wn,n,levels,b", N1_CASES)
+def test_wavelet_denoiser_rows_bit_exact(ctx, plan, wn, n, levels, b, mode, variant):
+    """WaveletDenoiser on short rows (denoising/WaveletDenoiser.java:121-167, 350-360): UNIVERSAL and MINIMAX (level-scaled
+    thresholds from sigma = MAD/0.6745) and the fixed form run in the single-launch row kernels; thresholds per (row, level)
+    and denoised rows must equal the oracle's and the three-launch path's bits."""
+    from vectorwave_amd import BoundaryMode, ThresholdType, WaveletDenoiser
+    if variant == "lds":
+        plan("no_band_regs", 1)
+    elif variant == "mat":
+        plan("no_row_denoise", 1)
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=3 * n + levels)
+    den = WaveletDenoiser(w, BoundaryMode(mode), ctx)
+    for method in (o.UNIVERSAL, o.MINIMAX):
+        for soft in (True, False):
+            st, want, want_thr = o.wavelet_denoise_batch(x, w, levels, method, soft, mode)
+            assert st == 0
+            got, thr = den.denoise_block(x, levels, method, ThresholdType.SOFT if soft else ThresholdType.HARD,
+                                         return_thresholds=True)
+            what = "%s %s N=%d J=%d mode=%d method=%d soft=%s" % (variant, wn, n, levels, mode, method, soft)
+            assert_bits_equal(thr, want_thr, "thresholds " + what)
+            assert_bits_equal(got, want, "denoised " + what)
+            if variant != "mat" and len(w.dec_lo) in (2, 4, 8) and n <= 1024:  # longer rows: by LDS need
+                assert "k_swt_denoise_row" in ctx.last_plan(), what
+    if levels == 0:
+        for thr_fixed in (0.25, 0.0):
+            for soft in (True, False):
+                st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, soft, mode, fixed_threshold=thr_fixed)
+                assert st == 0
+                got = den.denoise_block(x, 0, o.FIXED, ThresholdType.SOFT if soft else ThresholdType.HARD, fixed_threshold=thr_fixed)
+                assert_bits_equal(got, want, "%s fixed %r soft=%s" % (variant, thr_fixed, soft))
+        # a negative fixed threshold keeps the three-launch path (the row kernels read "negative" as "derive it")
+        st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, True, mode, fixed_threshold=-0.1)
+        got = den.denoise_block(x, 0, o.FIXED, ThresholdType.SOFT, fixed_threshold=-0.1)
+        assert_bits_equal(got, want, "%s negative fixed threshold" % variant)

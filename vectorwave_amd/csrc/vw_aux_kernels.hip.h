@@ -527,6 +527,17 @@ __global__ void __launch_bounds__(64) k_universal_threshold_reg(const MedianArgs
 // Needs: both decomposition filters and the low-pass reconstruction filter of exactly LT taps (LT even), the
 // reference's level limit (no filter longer than the row), n <= 64 * KPL.
 
+// WaveletDenoiser.calculateThreshold for the rules that are functions of sigma alone
+// (denoising/WaveletDenoiser.java:376-427): UNIVERSAL sigma * sqrt(2 ln n); MINIMAX piecewise in n
+__device__ __forceinline__ double denoiser_sigma_rule(int method, double sigma, int64_t n, double log_n) {
+    if (method == 2) {
+        if (n <= 32) return 0;
+        if (n <= 64) return sigma * 0.3936 + 0.1829 * sigma * log_n;
+        return sigma * (0.4745 + 0.1148 * log_n);
+    }
+    return sigma * sqrt(2.0 * log_n);
+}
+
 struct RowDenoiseArgs {
     const double* x;   // rows of length n
     int64_t x_stride;
@@ -538,8 +549,14 @@ struct RowDenoiseArgs {
     int32_t thr_mode;       // apply_thr mode: 1 soft, 2 hard
     double threshold;       // >= 0 (or NaN): fixed; < 0: universal threshold from |d_1|
     double sqrt_2_ln_n;
-    double* thr_out;        // [nrows] or nullptr
+    double* thr_out;        // rule 0: [nrows]; rule 1: [nrows][levels]; or nullptr
     int32_t vec;            // rows are 16-byte aligned and n is even: 16-byte global accesses
+    // rule 0: one threshold per row for every level (VectorWaveSwtAdapter.denoise; WaveletDenoiser.denoiseFixed).
+    // rule 1: WaveletDenoiser's per-level thresholds (denoising/WaveletDenoiser.java:121-167, 544-586): sigma =
+    // median(|d_1|) / 0.6745, divided by sqrt(2^(level-1)) when level_scaled, then the rule of `method`
+    // (VW_THRESHOLD_UNIVERSAL or VW_THRESHOLD_MINIMAX); `threshold` must be negative
+    int32_t rule, method, level_scaled;
+    double log_n;
     Taps dec, rec;          // decomposition (lo = h, hi = g) and reconstruction (lo = h~, hi = g~) taps, scaled
 };
 
@@ -607,6 +624,12 @@ __global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) 
     __syncthreads();
 
     double thr = a.threshold;
+    double sigma = 0.0;
+    auto level_thr = [&](int j) -> double {
+        if (a.rule == 0) return thr;
+        const double sj = a.level_scaled ? sigma / sqrt(static_cast<double>(1 << (j - 1))) : sigma;
+        return denoiser_sigma_rule(a.method, sj, a.n, a.log_n);
+    };
     double* in = bufA;
     double* out = bufB;
     // ---- forward cascade --------------------------------------------------------------------------------
@@ -614,6 +637,10 @@ __global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) 
         const int s = 1 << (j - 1);
         double* wj = wband + (j - 1) * ws;
         const bool thr_known = (j > 1) || !(a.threshold < 0);
+        if (j > 1 && a.rule != 0) {
+            thr = level_thr(j);
+            if (a.thr_out != nullptr && lane == 0) a.thr_out[row * J + (j - 1)] = thr;
+        }
 #pragma unroll
         for (int k0 = 0; k0 < KP; k0 += G) {
             bool live[G];
@@ -687,8 +714,9 @@ __global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) 
                 v[q] = i < n ? fabs(wj[i]) : reg_pad();
             }
             const double median = reg_median<KPL>(v, a.n);
-            const double sigma = median / 0.6745;
-            thr = sigma * a.sqrt_2_ln_n;
+            sigma = median / 0.6745;
+            thr = (a.rule == 0) ? sigma * a.sqrt_2_ln_n : level_thr(1);
+            if (a.rule != 0 && a.thr_out != nullptr && lane == 0) a.thr_out[row * J] = thr;
 #pragma unroll
             for (int q = 0; q < KPL; ++q) {
                 const int i = q * 64 + lane;
@@ -708,7 +736,7 @@ __global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) 
         in = out;
         out = t;
     }
-    if (a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
+    if (a.rule == 0 && a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
 
     // ---- inverse cascade: `in` holds R_J ------------------------------------------------------------------
     double* __restrict__ yrow = a.y + row * a.y_stride;
@@ -857,6 +885,12 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
     __syncthreads();
 
     double thr = a.threshold;
+    double sigma = 0.0;
+    auto level_thr = [&](int j) -> double {
+        if (a.rule == 0) return thr;
+        const double sj = a.level_scaled ? sigma / sqrt(static_cast<double>(1 << (j - 1))) : sigma;
+        return denoiser_sigma_rule(a.method, sj, a.n, a.log_n);
+    };
     double wreg[JMAX][KP][2];
     // ---- forward cascade, in place, chunk groups right to left ---------------------------------------------
 #pragma unroll
@@ -864,6 +898,10 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
         if (j <= J) {
             const int s = 1 << (j - 1);
             const bool thr_known = (j > 1) || !(a.threshold < 0);
+            if (j > 1 && a.rule != 0) {
+                thr = level_thr(j);
+                if (a.thr_out != nullptr && lane == 0) a.thr_out[row * J + (j - 1)] = thr;
+            }
 #pragma unroll
             for (int k0 = KP - GF; k0 >= 0; k0 -= GF) {
                 double av[GF][2];
@@ -929,8 +967,9 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
                         v[2 * k + 1] = q + 1 < n ? fabs(wreg[0][k][1]) : reg_pad();
                     }
                     const double median = reg_median<2 * KP>(v, a.n);
-                    const double sigma = median / 0.6745;
-                    thr = sigma * a.sqrt_2_ln_n;
+                    sigma = median / 0.6745;
+                    thr = (a.rule == 0) ? sigma * a.sqrt_2_ln_n : level_thr(1);
+                    if (a.rule != 0 && a.thr_out != nullptr && lane == 0) a.thr_out[row * J] = thr;
                 }
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
@@ -946,7 +985,7 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
             __syncthreads();
         }
     }
-    if (a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
+    if (a.rule == 0 && a.thr_out != nullptr && lane == 0) a.thr_out[row] = thr;
 
     // ---- inverse cascade, in place, chunks left to right ------------------------------------------------------
     double* __restrict__ yrow = a.y + row * a.y_stride;
@@ -1351,23 +1390,10 @@ __global__ void __launch_bounds__(kThreads) k_denoiser_thresholds(const Denoiser
     double sigma = a.sigma[row];
     if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (level - 1)));
     double* out = a.thr + row * a.levels + (level - 1);
-    const double universal = sigma * sqrt(2.0 * a.log_n);
+    const double universal = denoiser_sigma_rule(0, sigma, n, a.log_n);
 
-    if (a.method == 0) {
-        if (tid == 0) *out = universal;
-        return;
-    }
-    if (a.method == 2) {
-        if (tid == 0) {
-            double t;
-            if (n <= 32)
-                t = 0;
-            else if (n <= 64)
-                t = sigma * 0.3936 + 0.1829 * sigma * a.log_n;
-            else
-                t = sigma * (0.4745 + 0.1148 * a.log_n);
-            *out = t;
-        }
+    if (a.method == 0 || a.method == 2) {
+        if (tid == 0) *out = denoiser_sigma_rule(a.method, sigma, n, a.log_n);
         return;
     }
     if (a.method == 3) {

@@ -1428,9 +1428,15 @@ static void launch_row_denoise_k(const RowDenoiseArgs& a, int64_t n, int64_t b, 
         hipLaunchKernelGGL((k_swt_denoise_row<LT, 32, MODE>), grid, block, lds, s, a);
 }
 
+// rule 0: one threshold per row (fixed when threshold >= 0, else the SWT adapter's universal threshold); rule 1:
+// WaveletDenoiser's per-level thresholds from sigma (method UNIVERSAL or MINIMAX), thresholds_out_dev [b][levels]
+struct RowRule {
+    int rule = 0, method = 0, level_scaled = 0;
+    double log_n = 0.0;
+};
 static int row_denoise_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t n, int levels, const double* h, int lh, const double* g,
-                           const double* hr, const double* gr, int boundary, double threshold, double sqrt_2_ln_n, int soft,
-                           double* y_dev, double* thresholds_out_dev, hipStream_t s) {
+                           const double* hr, const double* gr, int boundary, double threshold, double sqrt_2_ln_n, int thr_mode,
+                           double* y_dev, double* thresholds_out_dev, hipStream_t s, const RowRule& rr = RowRule()) {
     if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
     RowDenoiseArgs a;
     memset(&a, 0, sizeof(a));
@@ -1441,10 +1447,14 @@ static int row_denoise_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t 
     a.n = n;
     a.nrows = b;
     a.levels = levels;
-    a.thr_mode = soft ? 1 : 2;
+    a.thr_mode = thr_mode;
     a.threshold = threshold;
     a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
     a.thr_out = thresholds_out_dev;
+    a.rule = rr.rule;
+    a.method = rr.method;
+    a.level_scaled = rr.level_scaled;
+    a.log_n = rr.log_n;
     a.vec = (n % 2 == 0) && aligned16(x_dev) && aligned16(y_dev);
     scale_taps(h, lh, a.dec.lo);
     scale_taps(g, lh, a.dec.hi);
@@ -1492,7 +1502,7 @@ extern "C" int32_t vw_swt_denoise_batch_dev(vw_ctx* ctx, const double* x_dev, in
         return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
     // short rows: the whole decomposition of a row stays in LDS, no workspace is touched
     if (row_denoise_eligible(ctx, n, levels, lh, lg, lhr, lgr, boundary))
-        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft ? 1 : 2, y_dev,
                                thresholds_out_dev, s);
     char* wsb;
     if (workspace_dev != nullptr) {
@@ -1523,7 +1533,7 @@ extern "C" int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx* ctx, const double* x
         // short rows need no scratch at all: the decomposition of a row never leaves LDS
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
         VW_HIP(ctx, hipSetDevice(ctx->device));
-        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft, y_dev,
+        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, threshold, sqrt_2_ln_n, soft ? 1 : 2, y_dev,
                                thresholds_out_dev, static_cast<hipStream_t>(stream));
     }
     const size_t need = round256(vw_swt_denoise_workspace_bytes(b, n, levels));
@@ -1761,6 +1771,21 @@ extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // short rows, rules that are functions of sigma alone (or a fixed threshold): the single-launch row kernels, in the
+    // reference's arithmetic only
+    if (!(flags & VW_FLAG_FMA) && row_denoise_eligible(ctx, n, levels, lh, lg, lhr, lgr, boundary) &&
+        (method == VW_THRESHOLD_UNIVERSAL || method == VW_THRESHOLD_MINIMAX ||
+         (method == VW_THRESHOLD_FIXED && !(fixed_threshold < 0)))) {
+        RowRule rr;
+        const bool fixed = method == VW_THRESHOLD_FIXED;
+        rr.rule = fixed ? 0 : 1;
+        rr.method = method;
+        rr.level_scaled = single ? 0 : 1;
+        rr.log_n = log_n < 0 ? log(static_cast<double>(n)) : log_n;
+        // a fixed threshold applies to the single level the fixed form has; thresholds_out is [b][levels] either way
+        return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, fixed ? fixed_threshold : -1.0, 0.0,
+                               soft ? 3 : 2, y_dev, thresholds_out_dev, s, rr);
+    }
     const size_t need = vw_wavelet_denoise_workspace_bytes(b, n, levels);
     char* wsb;
     if (workspace_dev != nullptr) {
