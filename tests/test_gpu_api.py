@@ -247,3 +247,67 @@ def test_page_locked_host_buffers(ctx):
     assert ctx.lib.vw_host_free(ctx.handle, ptr) == N.VW_OK
     assert ctx.lib.vw_host_free(ctx.handle, None) == N.VW_OK
     assert ctx.lib.vw_host_alloc(ctx.handle, 16, None) == N.VW_E_NULL
+
+
+@pytest.mark.parametrize("mode", [PER, ZP, SYM])
+@pytest.mark.parametrize("wn,n,j", [("haar", 64, 3), ("db4", 256, 4), ("db4", 777, 3), ("sym8", 3000, 5), ("bior2.2", 200, 2)])
+def test_facade_packing_bit_exact(ctx, wn, n, j, mode):
+    """What the mirror classes hand out -- which array is the detail, which the approximation, which level a band
+    belongs to, what a partial reconstruction zeroes -- compared with the oracle bit for bit, so a swapped or shifted
+    band in the host-side packing cannot hide behind a reconstruction tolerance
+    (modwt/MODWTTransform.java:123-291, modwt/MultiLevelMODWTTransform.java:200-468, swt/VectorWaveSwtAdapter.java:122-348)."""
+    from oracle import oracle as o
+    from util import assert_bits_equal
+    w = get_wavelet(wn)
+    xs = signals(3, n, seed=n + j)
+    x = xs[0]
+    # single level
+    t = MODWTTransform(wn, mode, ctx)
+    want1 = o.modwt_forward_batch(xs, w, int(mode))
+    r = t.forward(x)
+    assert_bits_equal(r.detailCoeffs(), want1[0, 0], "forward: detail")
+    assert_bits_equal(r.approximationCoeffs(), want1[0, 1], "forward: approximation")
+    assert_bits_equal(t.inverse(r), o.modwt_inverse_batch(want1[:1], w, int(mode), batch_variant=0)[0], "inverse")
+    if len(w.rec_lo) == len(w.rec_hi):
+        for i, rb in enumerate(t.forwardBatch(xs)):
+            assert_bits_equal(rb.detailCoeffs(), want1[i, 0], "forwardBatch: detail %d" % i)
+            assert_bits_equal(rb.approximationCoeffs(), want1[i, 1], "forwardBatch: approximation %d" % i)
+    # multi-level
+    m = MultiLevelMODWTTransform(wn, mode, ctx)
+    st, want = o.decompose_batch(xs, w, j, int(mode))
+    assert st == 0
+    for res in (m.decompose(x, j), m.decomposeMutable(x, j)):
+        for lev in range(1, j + 1):
+            assert_bits_equal(res.getDetailCoeffsAtLevel(lev), want[0, lev - 1], "decompose: detail level %d" % lev)
+        assert_bits_equal(res.getApproximationCoeffs(), want[0, j], "decompose: approximation")
+    res = m.decompose(x, j)
+    if len(w.rec_lo) == len(w.rec_hi):
+        assert_bits_equal(m.reconstruct(res), o.reconstruct_batch(want[:1], w, int(mode))[0], "reconstruct")
+        for k in range(1, j + 1):
+            z = want[:1].copy()
+            z[0, :k - 1] = 0.0  # reconstructFromLevel(k): details finer than k dropped
+            assert_bits_equal(m.reconstructFromLevel(res, k), o.reconstruct_batch(z, w, int(mode))[0], "reconstructFromLevel(%d)" % k)
+            z = np.zeros_like(want[:1])
+            z[0, k - 1] = want[0, k - 1]  # reconstructLevels(k, k): that detail band alone ...
+            if k == j:
+                z[0, j] = want[0, j]  # ... with the approximation when the range reaches the top level
+            assert_bits_equal(m.reconstructLevels(res, k, k), o.reconstruct_batch(z, w, int(mode))[0], "reconstructLevels(%d,%d)" % (k, k))
+        for i, rb in enumerate(m.decomposeBatch(xs, j)):
+            for lev in range(1, j + 1):
+                assert_bits_equal(rb.getDetailCoeffsAtLevel(lev), want[i, lev - 1], "decomposeBatch: row %d level %d" % (i, lev))
+            assert_bits_equal(rb.getApproximationCoeffs(), want[i, j], "decomposeBatch: row %d approximation" % i)
+    # SWT adapter
+    if mode != SYM and len(w.rec_lo) == len(w.rec_hi):
+        a = VectorWaveSwtAdapter(wn, mode, ctx)
+        sres = a.forward(x, j)
+        for lev in range(1, j + 1):
+            assert_bits_equal(sres.getDetailCoeffsAtLevel(lev), want[0, lev - 1], "swt forward: level %d" % lev)
+        for soft in (True, False):
+            st, wd = o.swt_denoise_batch(xs, w, j, -1.0, soft, int(mode))
+            assert st == 0
+            assert_bits_equal(a.denoise(x, j, -1, soft), wd[0], "swt denoise soft=%s" % soft)
+        for k in range(0, j + 1):
+            z = np.zeros_like(want[:1])
+            band = j if k == 0 else k - 1  # extractLevel(0) keeps the approximation alone
+            z[0, band] = want[0, band]
+            assert_bits_equal(a.extractLevel(x, j, k), o.reconstruct_batch(z, w, int(mode))[0], "extractLevel(%d)" % k)
