@@ -108,3 +108,37 @@ def test_wavelet_denoiser_rows_bit_exact(ctx, plan, wn, n, levels, b, mode, vari
         st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, True, mode, fixed_threshold=-0.1)
         got = den.denoise_block(x, 0, o.FIXED, ThresholdType.SOFT, fixed_threshold=-0.1)
         assert_bits_equal(got, want, "%s negative fixed threshold" % variant)
+
+
+@pytest.mark.parametrize("variant", ["regs", "lds", "mat"])
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("wn", ["db4", "haar", "db2"])
+def test_row_denoise_special_values(ctx, plan, wn, mode, variant):
+    """Rows that steer the single-launch kernels between their short thresholding form (finite, moderate samples) and
+    the general one: all zeros, negative zeros, subnormals, values beyond 2^500 that stay finite, thresholds that
+    shrink every coefficient to zero, a threshold of exactly zero -- zero signs included, every output bit must be
+    the oracle's (swt/VectorWaveSwtAdapter.java:255-312)."""
+    if variant == "lds":
+        plan("no_band_regs", 1)
+    elif variant == "mat":
+        plan("no_row_denoise", 1)
+    w = get_wavelet(wn)
+    n, j = 480, 4
+    x = signals(12, n, seed=91)
+    x[0] = 0.0
+    x[1] = -0.0
+    x[2] = np.where(np.arange(n) % 3 == 0, -0.0, 0.0)
+    x[3] *= 5e-324 / np.abs(x[3]).max() * 40  # subnormals of a few dozen units
+    x[4] *= 1e-310
+    x[5] *= 1e200     # beyond the short form's bound, finite throughout
+    x[6] *= 1e-200
+    x[7, ::2] = 0.0   # half of the finest details are small
+    x[8] = 1.0        # constant row: every detail coefficient is a rounding residue
+    x[9] = -np.abs(x[9])
+    x[10, 100] = 3e180
+    for thr, soft in ((-1.0, True), (-1.0, False), (0.0, True), (0.0, False), (1e300, True), (1e300, False), (2.5, True)):
+        st, want = o.swt_denoise_batch(x, w, j, thr, soft, mode)
+        assert st == 0
+        st, got, _ = gpu_denoise(ctx, x, wn, j, mode, thr, soft)
+        assert st == N.VW_OK, ctx.last_error()
+        assert_bits_equal(got, want, "%s %s mode=%d thr=%r soft=%s" % (variant, wn, mode, thr, soft))

@@ -312,26 +312,48 @@ __device__ __forceinline__ unsigned long long sum_nt(unsigned long long v, SelLd
 // unit), no barriers; bits that all keys share are skipped, and the descent stops as soon as one key is
 // left in the range.
 
-// bits resolved per descent step: 2 costs three threshold counts per step, 1 costs one; per bit the single
-// threshold is cheaper (62 against 66 microseconds for the MAD of 8192 rings of 1024)
-constexpr int kSelectBitsPerStep = 1;
-
 __device__ __forceinline__ double reg_pad() { return __longlong_as_double(-1ll); }
 
+// Reductions over the wavefront that end on the scalar unit (every lane of the wavefront must be active): four DPP
+// steps -- neighbour, other pair, mirrored half row, mirrored row -- leave each row of 16 lanes with its own result,
+// and the four rows are combined from scalar registers.  No LDS traffic (a shuffle is an LDS instruction with its
+// latency), and the result is known to the compiler as wave-uniform, so what is derived from it (the bit position,
+// the prefix, the counts, the loop of the descent) lives in scalar registers and branches on the scalar unit.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ unsigned lane_u32(unsigned v, int lane) {
+    return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), lane));
+}
+constexpr int kDppSwap1 = 0xb1, kDppSwap2 = 0x4e, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
 __device__ __forceinline__ unsigned wave_and_u32(unsigned v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v &= __shfl_xor(v, d, 64);
-    return v;
+    v &= dpp_u32<kDppSwap1>(v);
+    v &= dpp_u32<kDppSwap2>(v);
+    v &= dpp_u32<kDppHalfMirror>(v);
+    v &= dpp_u32<kDppMirror>(v);
+    return (lane_u32(v, 0) & lane_u32(v, 16)) & (lane_u32(v, 32) & lane_u32(v, 48));
 }
 
 __device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
-    return v;
+    v |= dpp_u32<kDppSwap1>(v);
+    v |= dpp_u32<kDppSwap2>(v);
+    v |= dpp_u32<kDppHalfMirror>(v);
+    v |= dpp_u32<kDppMirror>(v);
+    return (lane_u32(v, 0) | lane_u32(v, 16)) | (lane_u32(v, 32) | lane_u32(v, 48));
 }
 
-// keys below threshold t; HI32: the low word of t is zero, so the high words decide (a 32-bit compare per key
-// instead of a 64-bit one)
+__device__ __forceinline__ unsigned wave_umin_u32(unsigned v) {
+    v = min(v, dpp_u32<kDppSwap1>(v));
+    v = min(v, dpp_u32<kDppSwap2>(v));
+    v = min(v, dpp_u32<kDppHalfMirror>(v));
+    v = min(v, dpp_u32<kDppMirror>(v));
+    return min(min(lane_u32(v, 0), lane_u32(v, 16)), min(lane_u32(v, 32), lane_u32(v, 48)));
+}
+
+// keys below the wave-uniform threshold t; HI32: the low word of t is zero, so the high words decide (a 32-bit compare
+// per key instead of a 64-bit one)
 template <int KPL, bool HI32>
 __device__ __forceinline__ unsigned count_below(const double (&v)[KPL], unsigned long long t) {
     unsigned c = 0;
@@ -345,6 +367,7 @@ __device__ __forceinline__ unsigned count_below(const double (&v)[KPL], unsigned
     return c;
 }
 
+// the key of rank k (0-based) among the n keys of the row; n and k are the same in every lane
 template <int KPL>
 __device__ __forceinline__ unsigned long long reg_select(const double (&v)[KPL], int64_t n, int64_t k) {
     unsigned ah = ~0u, al = ~0u, oh = 0u, ol = 0u;
@@ -363,52 +386,38 @@ __device__ __forceinline__ unsigned long long reg_select(const double (&v)[KPL],
     if (diff == 0) return all_and;  // every key is the same
     int pos = 64 - __clzll(static_cast<long long>(diff));  // bits [0, pos) are undecided
     unsigned long long prefix = pos >= 64 ? 0ull : (all_and & (~0ull << pos));
-    unsigned below = 0;                        // keys under the current range
-    unsigned in_range = static_cast<unsigned>(n);
-    const unsigned kk = static_cast<unsigned>(k);
+    unsigned below = 0;  // keys under the current range
+    unsigned in_range = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(n)));
+    const unsigned kk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
 #pragma unroll 1
     while (pos > 0 && in_range > 1) {
-        const int step = (kSelectBitsPerStep == 2 && pos >= 2) ? 2 : 1;
-        pos -= step;
-        unsigned c1, c2 = below + in_range, c3 = below + in_range;
-        if (pos >= 32) {
-            c1 = count_below<KPL, true>(v, prefix | (1ull << pos));
-            if (step == 2) {
-                c2 = count_below<KPL, true>(v, prefix | (2ull << pos));
-                c3 = count_below<KPL, true>(v, prefix | (3ull << pos));
-            }
-        } else {
-            c1 = count_below<KPL, false>(v, prefix | (1ull << pos));
-            if (step == 2) {
-                c2 = count_below<KPL, false>(v, prefix | (2ull << pos));
-                c3 = count_below<KPL, false>(v, prefix | (3ull << pos));
-            }
-        }
-        const unsigned end = below + in_range;
-        unsigned q, lo_c, hi_c;
+        --pos;
+        const unsigned long long t = prefix | (1ull << pos);
+        const unsigned c1 = (pos >= 32) ? count_below<KPL, true>(v, t) : count_below<KPL, false>(v, t);
         if (kk < c1) {
-            q = 0; lo_c = below; hi_c = c1;
-        } else if (kk < c2) {
-            q = 1; lo_c = c1; hi_c = c2;
-        } else if (kk < c3) {
-            q = 2; lo_c = c2; hi_c = c3;
+            in_range = c1 - below;
         } else {
-            q = 3; lo_c = c3; hi_c = end;
+            prefix = t;
+            in_range = below + in_range - c1;
+            below = c1;
         }
-        prefix |= static_cast<unsigned long long>(q) << pos;
-        below = lo_c;
-        in_range = hi_c - lo_c;
     }
     if (pos == 0) return prefix;
-    // one key left in [prefix, prefix + 2^pos): it is the answer
+    // one key left in [prefix, prefix + 2^pos): one lane holds it in one slot
     const unsigned long long mask = ~0ull << pos;
-    unsigned long long found = ~0ull;
+    unsigned fh = 0u, fl = 0u;
+    bool mine = false;
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
         const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
-        if ((key & mask) == prefix) found = key;
+        if ((key & mask) == prefix) {
+            fh = static_cast<unsigned>(key >> 32);
+            fl = static_cast<unsigned>(key);
+            mine = true;
+        }
     }
-    return wave_min_u64(found);
+    const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine));
+    return (static_cast<unsigned long long>(lane_u32(fh, src)) << 32) | lane_u32(fl, src);
 }
 
 // median the way the reference takes it from a sorted copy (mean of the two middle elements for even n)
@@ -417,18 +426,26 @@ __device__ __forceinline__ double reg_median(const double (&v)[KPL], int64_t n) 
     const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
     const unsigned long long v1 = reg_select<KPL>(v, n, k1);
     if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
-    unsigned long long le = 0, above = ~0ull;
+    // rank k1 + 1: v1 again when at least k1 + 2 keys are <= v1, else the smallest key above v1
+    unsigned le = 0;
+    unsigned ah = ~0u, al = ~0u;  // the lane's smallest key above v1
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
         const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
-        if (key <= v1)
-            ++le;
-        else if (key < above)
-            above = key;
+        const bool gt = key > v1;
+        le += static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(!gt)));
+        const unsigned long long cur = (static_cast<unsigned long long>(ah) << 32) | al;
+        if (gt && key < cur) {
+            ah = static_cast<unsigned>(key >> 32);
+            al = static_cast<unsigned>(key);
+        }
     }
-    le = wave_sum_u64(le);
-    above = wave_min_u64(above);
-    const unsigned long long v2 = (static_cast<int64_t>(le) >= k1 + 2) ? v1 : above;
+    unsigned long long v2 = v1;
+    if (static_cast<int64_t>(le) < k1 + 2) {
+        const unsigned mh = wave_umin_u32(ah);
+        const unsigned ml = wave_umin_u32(ah == mh ? al : ~0u);
+        v2 = (static_cast<unsigned long long>(mh) << 32) | ml;
+    }
     return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
 }
 
@@ -538,6 +555,17 @@ __device__ __forceinline__ double denoiser_sigma_rule(int method, double sigma, 
     return sigma * sqrt(2.0 * log_n);
 }
 
+// Thresholding when coefficient and threshold are known to be finite and the threshold is not negative: the three
+// forms of apply_thr then agree, and soft thresholding is max(|c| - thr, 0) with the sign of c -- three instructions
+// instead of a dozen.  A coefficient that shrinks to zero may come out as -0.0 where apply_thr gives +0.0; callers use
+// this only where the value feeds an inverse cascade and nothing else: every reconstruction sum starts from +0.0,
+// (+0.0) + (-0.0) is +0.0 and a nonzero term is not changed by a zero of either sign, so the sign of a zero
+// coefficient cannot reach an output.
+__device__ __forceinline__ double shrink_finite(double c, double thr, bool soft) {
+    if (!soft) return (fabs(c) <= thr) ? 0.0 : c;
+    return __builtin_copysign(__builtin_fmax(fabs(c) - thr, 0.0), c);
+}
+
 struct RowDenoiseArgs {
     const double* x;   // rows of length n
     int64_t x_stride;
@@ -557,6 +585,7 @@ struct RowDenoiseArgs {
     // (VW_THRESHOLD_UNIVERSAL or VW_THRESHOLD_MINIMAX); `threshold` must be negative
     int32_t rule, method, level_scaled;
     double log_n;
+    int32_t taps_small;     // every scaled tap is at most 2^20 in magnitude (the host checks): see shrink_finite
     Taps dec, rec;          // decomposition (lo = h, hi = g) and reconstruction (lo = h~, hi = g~) taps, scaled
 };
 
@@ -867,6 +896,7 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
         p[k] = live[k] ? q : np - 2;  // lanes beyond the row compute on its last pair and do not write
     }
 
+    bool tame = true;
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (live[k]) {
@@ -878,11 +908,17 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
                 v.y = (p[k] + 1 < n) ? xrow[p[k] + 1] : 0.0;
             }
             *reinterpret_cast<double2*>(sig + p[k]) = v;
+            tame = tame && fabs(v.x) < 0x1p500 && fabs(v.y) < 0x1p500;
         }
     }
     __syncthreads();
     fill_left(sig, LT - 1);
     __syncthreads();
+    // Samples below 2^500 and taps of at most 2^20: eight levels of sums of at most sixteen products stay below
+    // 2^(500 + 8 * 24), so every coefficient of this row is finite and shrink_finite applies whenever the threshold is
+    // finite and not negative (a NaN sample fails the comparison above).
+    const bool calm = a.taps_small != 0 && __builtin_amdgcn_ballot_w64(!tame) == 0;
+    const bool soft = a.thr_mode != 2;
 
     double thr = a.threshold;
     double sigma = 0.0;
@@ -891,6 +927,12 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
         const double sj = a.level_scaled ? sigma / sqrt(static_cast<double>(1 << (j - 1))) : sigma;
         return denoiser_sigma_rule(a.method, sj, a.n, a.log_n);
     };
+    // wave-uniform: the current threshold allows the short form
+    auto quick_now = [&]() -> bool {
+        return __builtin_amdgcn_readfirstlane(static_cast<int>(calm && thr >= 0.0 && thr <= 0x1.fffffffffffffp1023)) != 0;
+    };
+    bool quick = quick_now();
+    auto shrink = [&](double c) -> double { return quick ? shrink_finite(c, thr, soft) : apply_thr(c, thr, a.thr_mode); };
     double wreg[JMAX][KP][2];
     // ---- forward cascade, in place, chunk groups right to left ---------------------------------------------
 #pragma unroll
@@ -900,6 +942,7 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
             const bool thr_known = (j > 1) || !(a.threshold < 0);
             if (j > 1 && a.rule != 0) {
                 thr = level_thr(j);
+                quick = quick_now();
                 if (a.thr_out != nullptr && lane == 0) a.thr_out[row * J + (j - 1)] = thr;
             }
 #pragma unroll
@@ -947,8 +990,8 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
                             w0 = w0 + xt[g][l].x * dh[l];
                             w1 = w1 + xt[g][l].y * dh[l];
                         }
-                        wreg[j - 1][k0 + g][0] = thr_known ? apply_thr(w0, thr, a.thr_mode) : w0;
-                        wreg[j - 1][k0 + g][1] = thr_known ? apply_thr(w1, thr, a.thr_mode) : w1;
+                        wreg[j - 1][k0 + g][0] = thr_known ? shrink(w0) : w0;
+                        wreg[j - 1][k0 + g][1] = thr_known ? shrink(w1) : w1;
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -969,12 +1012,13 @@ __global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs 
                     const double median = reg_median<2 * KP>(v, a.n);
                     sigma = median / 0.6745;
                     thr = (a.rule == 0) ? sigma * a.sqrt_2_ln_n : level_thr(1);
+                    quick = quick_now();
                     if (a.rule != 0 && a.thr_out != nullptr && lane == 0) a.thr_out[row * J] = thr;
                 }
 #pragma unroll
                 for (int k = 0; k < KP; ++k) {
-                    wreg[0][k][0] = apply_thr(wreg[0][k][0], thr, a.thr_mode);
-                    wreg[0][k][1] = apply_thr(wreg[0][k][1], thr, a.thr_mode);
+                    wreg[0][k][0] = shrink(wreg[0][k][0]);
+                    wreg[0][k][1] = shrink(wreg[0][k][1]);
                 }
             }
             __syncthreads();

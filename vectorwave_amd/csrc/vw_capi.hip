@@ -1460,6 +1460,10 @@ static int row_denoise_dev(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t 
     scale_taps(g, lh, a.dec.hi);
     scale_taps(hr, lh, a.rec.lo);
     scale_taps(gr, lh, a.rec.hi);
+    a.taps_small = 1;
+    for (int l = 0; l < lh; ++l)
+        for (const double t : {a.dec.lo[l], a.dec.hi[l], a.rec.lo[l], a.rec.hi[l]})
+            if (!(fabs(t) <= 0x1p20)) a.taps_small = 0;
     // rows of up to 512 samples at up to four levels keep their detail bands in registers (one band buffer in LDS)
     const bool regs = n <= 512 && levels <= 4 && !ctx->opt.no_band_regs;
     ctx->plan_fwd[0] = ctx->plan_inv[0] = 0;
