@@ -260,7 +260,7 @@ __device__ __forceinline__ double mac(double acc, double x, double f) {
     return FMA ? __builtin_fma(x, f, acc) : acc + x * f;
 }
 
-template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI, bool FMA, bool FIRST = false, int CH = kChunk>
+template <int PPT, int HPT, bool S1, bool DO_LO, bool DO_HI, bool FMA, bool FIRST = false, int CH = kChunk, bool HALO_HERE = true>
 __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&hbase)[HPT], int off, double flo,
                                         double fhi, double (&av)[PPT][2], double (&aw)[PPT][2],
                                         double (&ah)[HPT][2], double (&xp)[PPT], double (&xph)[HPT],
@@ -289,7 +289,7 @@ __device__ __forceinline__ void fwd_tap(const char* lds, int baseT, const int (&
             aw[k][1] = mac<FMA>(FIRST ? 0.0 : aw[k][1], xt[k].y, fhi);
         }
     }
-    if (DO_LO) {
+    if (DO_LO && HALO_HERE) {
 #pragma unroll
         for (int c = 0; c < HPT; ++c) {
             if (wact[c]) {  // wave-uniform
@@ -336,11 +336,39 @@ __device__ __forceinline__ void fwd_level(const char* lds, const FwdArgs& a, int
             tl[i] = a.taps.lo[i];
             th[i] = a.taps.hi[i];
         }
-        fwd_tap<PPT, HPT, S1, true, true, FMA, true, CH>(lds, baseT, hbase, 0, tl[0], th[0], av, aw, ah, xp, xph, wact);
+        fwd_tap<PPT, HPT, S1, true, true, FMA, true, CH, false>(lds, baseT, hbase, 0, tl[0], th[0], av, aw, ah, xp, xph, wact);
 #pragma unroll
         for (int i = 1; i < LT; ++i)
-            fwd_tap<PPT, HPT, S1, true, true, FMA, false, CH>(lds, baseT, hbase, i * sb, tl[i], th[i], av, aw, ah, xp,
-                                                              xph, wact);
+            fwd_tap<PPT, HPT, S1, true, true, FMA, false, CH, false>(lds, baseT, hbase, i * sb, tl[i], th[i], av, aw, ah, xp,
+                                                                     xph, wact);
+        // The halo chunks (low-pass only, wave-uniform switch) after the tile, each behind ONE branch with its
+        // operands requested together: inside the tap loop every tap cost every wave a branch, and a wave with an
+        // active halo chunk waited for its tile operands tap by tap.
+#pragma unroll
+        for (int c = 0; c < HPT; ++c) {
+            if (wact[c]) {
+                if (S1) {
+                    double d[LT > 0 ? LT + 1 : 1];
+#pragma unroll
+                    for (int m = 1; m <= LT; ++m) d[m] = *reinterpret_cast<const double*>(lds + hbase[c] + 8 - m * 8);
+                    d[0] = xph[c];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) {
+                        ah[c][0] = mac<FMA>(ah[c][0], d[i + 1], tl[i]);
+                        ah[c][1] = mac<FMA>(ah[c][1], d[i], tl[i]);
+                    }
+                } else {
+                    double2 x[LT > 0 ? LT : 1];
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) x[i] = *reinterpret_cast<const double2*>(lds + hbase[c] - i * sb);
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) {
+                        ah[c][0] = mac<FMA>(ah[c][0], x[i].x, tl[i]);
+                        ah[c][1] = mac<FMA>(ah[c][1], x[i].y, tl[i]);
+                    }
+                }
+            }
+        }
         return;
     }
     const int lh = a.lh, lg = a.lg;
