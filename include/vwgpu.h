@@ -126,6 +126,8 @@ int32_t vw_device_count(void);
  * "inv_tile" (value = chunks per tile * 100 + halo chunks, e.g. 401; 0 = planner's choice), "fwd_chunks"
  * (tiles per run of the streaming forward), "stream_wgs" (workgroups wanted per streaming launch),
  * "sdry_chunks" (run length of the long-context kernels), "no_sdry", "no_unroll", "no_reg_select",
+ * "no_wg_select" (0/1: rows of 2049..32768 samples through the 256-lane radix select),
+ * "select_lds_cap" (longest row the 256-lane selection kernel copies into LDS; 0 = all that fits),
  * "no_std_chains", "no_wide_inv", "no_vec2" (0/1), "no_ring" / "no_blk" (0/1: inverse tile kernel without the
  * LDS-DMA band ring / without register-blocked windows), "carry_chunks" (>= 2: the ring kernel over runs of that
  * many tiles with the right context carried from tile to tile; 0 = one tile per workgroup, the default),

@@ -213,12 +213,20 @@ def test_median_with_duplicates_and_zeros(ctx):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 127, 128, 256, 257, 480, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095,
-                               4097, 5000])
-def test_median_selection_edge_cases(ctx, n):
-    # every row-length class of the selection kernels (registers up to 2048 samples, LDS up to 4096, global
-    # beyond), with the value patterns that stress an order-statistic search: few distinct values, one
-    # outlier, denormals next to huge values, powers of two (keys that differ in one bit), signed zeros,
-    # values that differ only in the last mantissa bit
+                               4097, 5000, 8192, 8193, 16384, 16385, 18431, 18432, 18433, 32767, 32768, 32769,
+                               (2049, 0), (4096, 0), (5000, 0), (16384, 0), (18433, 0), (5000, 4096), (2049, 2048)])
+def test_median_selection_edge_cases(ctx, plan, n):
+    # every row-length class of the selection kernels (registers of one wave up to 2048 samples, of one workgroup
+    # up to 4096 / 8192 / 16384 / 32768, radix select reading global memory beyond; a pair (n, cap) sends the row
+    # through the 256-lane radix select instead, staged in LDS up to 18432 samples -- or up to cap, if not zero --
+    # and reading global memory beyond), with the value patterns that stress an order-statistic search: few
+    # distinct values, one outlier, denormals next to huge values, powers of two (keys that differ in one bit),
+    # signed zeros, values that differ only in the last mantissa bit
+    if isinstance(n, tuple):
+        n, cap = n
+        plan("no_wg_select", 1)
+        if cap:
+            plan("select_lds_cap", cap)
     rng = np.random.default_rng(n)
     rows = [
         rng.standard_normal(n),

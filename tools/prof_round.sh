@@ -9,7 +9,7 @@
 tag=$1
 R=/root/repo
 out=$R/gpurun_out/$tag
-mkdir -p $out
+mkdir -p $out $out/traffic
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 $R/bench.py > $out/bench_default.json 2> $out/bench_default.err || { echo "bench failed"; tail -5 $out/bench_default.err; exit 1; }
 cut -c1-600 $out/bench_default.json

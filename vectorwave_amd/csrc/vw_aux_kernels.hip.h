@@ -507,6 +507,166 @@ __global__ void __launch_bounds__(NT) k_universal_threshold(const MedianArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------
+// rows of up to NT * KPL samples in the registers of one workgroup (NT = 256 or 1024 lanes)
+// ---------------------------------------------------------------------------
+//
+// The threshold-count descent of reg_select with the count of a step summed over the waves of the workgroup:
+// every wave counts its keys below the threshold with ballots (a scalar per wave), lane 0 puts it into the wave's
+// LDS cell, one barrier, every lane adds up the cells.  The cells are double-buffered by the parity of the step,
+// so a step needs one barrier: a wave can only overwrite a buffer after the barrier of the step in between, which
+// every wave reaches after it has read that buffer.  The row is read from HBM exactly once (the 256-lane radix
+// select reads a row longer than its LDS stage nine times, and its LDS histogram serialises on the one bin that
+// nearly all keys of a band share in the high-order passes: 3.07 ms for 16384 rows of 16384 samples).
+template <int NW>
+struct WgCells {
+    unsigned long long x[2][NW];
+    unsigned long long y[2][NW];
+};
+
+template <int NW, class FX, class FY>
+__device__ __forceinline__ void wg_combine2(unsigned long long& x, unsigned long long& y, FX fx, FY fy, WgCells<NW>& c, int& par) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        c.x[par][wave] = x;
+        c.y[par][wave] = y;
+    }
+    __syncthreads();
+    unsigned long long rx = c.x[par][0], ry = c.y[par][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        rx = fx(rx, c.x[par][w]);
+        ry = fy(ry, c.y[par][w]);
+    }
+    x = rx;
+    y = ry;
+    par ^= 1;
+}
+
+template <int NW, class FX>
+__device__ __forceinline__ unsigned long long wg_combine1(unsigned long long x, FX fx, WgCells<NW>& c, int& par) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) c.x[par][wave] = x;
+    __syncthreads();
+    unsigned long long rx = c.x[par][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) rx = fx(rx, c.x[par][w]);
+    par ^= 1;
+    return rx;
+}
+
+// the key of rank k (0-based) among the n keys of the row held by the whole workgroup (padding = reg_pad())
+template <int NW, int KPL>
+__device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], int64_t n, int64_t k, WgCells<NW>& cells, int& par) {
+    unsigned ah = ~0u, al = ~0u, oh = 0u, ol = 0u;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned hi = static_cast<unsigned>(__double2hiint(v[j])), lo = static_cast<unsigned>(__double2loint(v[j]));
+        const bool valid = static_cast<int>(hi) >= 0;
+        ah &= hi;
+        al &= lo;
+        oh |= valid ? hi : 0u;
+        ol |= valid ? lo : 0u;
+    }
+    unsigned long long all_and = (static_cast<unsigned long long>(wave_and_u32(ah)) << 32) | wave_and_u32(al);
+    unsigned long long all_or = (static_cast<unsigned long long>(wave_or_u32(oh)) << 32) | wave_or_u32(ol);
+    wg_combine2<NW>(all_and, all_or, [](unsigned long long p, unsigned long long q) { return p & q; },
+                    [](unsigned long long p, unsigned long long q) { return p | q; }, cells, par);
+    const unsigned long long diff = all_and ^ all_or;
+    if (diff == 0) return all_and;  // every key is the same
+    int pos = 64 - __clzll(static_cast<long long>(diff));  // bits [0, pos) are undecided
+    unsigned long long prefix = pos >= 64 ? 0ull : (all_and & (~0ull << pos));
+    unsigned below = 0;
+    unsigned in_range = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(n)));
+    const unsigned kk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
+#pragma unroll 1
+    while (pos > 0 && in_range > 1) {
+        --pos;
+        const unsigned long long t = prefix | (1ull << pos);
+        const unsigned cw = (pos >= 32) ? count_below<KPL, true>(v, t) : count_below<KPL, false>(v, t);
+        const unsigned c1 = static_cast<unsigned>(
+            wg_combine1<NW>(cw, [](unsigned long long p, unsigned long long q) { return p + q; }, cells, par));
+        if (kk < c1) {
+            in_range = c1 - below;
+        } else {
+            prefix = t;
+            in_range = below + in_range - c1;
+            below = c1;
+        }
+    }
+    if (pos == 0) return prefix;
+    // one key left in [prefix, prefix + 2^pos): one lane of one wave holds it
+    const unsigned long long mask = ~0ull << pos;
+    unsigned fh = 0u, fl = 0u;
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
+        if ((key & mask) == prefix) {
+            fh = static_cast<unsigned>(key >> 32);
+            fl = static_cast<unsigned>(key);
+            mine = true;
+        }
+    }
+    const unsigned long long who = __builtin_amdgcn_ballot_w64(mine);
+    unsigned long long found = ~0ull;
+    if (who != 0) {
+        const int src = __builtin_ctzll(who);
+        found = (static_cast<unsigned long long>(lane_u32(fh, src)) << 32) | lane_u32(fl, src);
+    }
+    return wg_combine1<NW>(found, [](unsigned long long p, unsigned long long q) { return p < q ? p : q; }, cells, par);
+}
+
+template <int NW, int KPL>
+__device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, WgCells<NW>& cells, int& par) {
+    const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
+    const unsigned long long v1 = wg_select<NW, KPL>(v, n, k1, cells, par);
+    if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
+    // rank k1 + 1: v1 again when at least k1 + 2 keys are <= v1, else the smallest key above v1
+    unsigned le = 0;
+    unsigned ah = ~0u, al = ~0u;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(v[j]));
+        const bool gt = key > v1;
+        le += static_cast<unsigned>(__popcll(__builtin_amdgcn_ballot_w64(!gt)));
+        const unsigned long long cur = (static_cast<unsigned long long>(ah) << 32) | al;
+        if (gt && key < cur) {
+            ah = static_cast<unsigned>(key >> 32);
+            al = static_cast<unsigned>(key);
+        }
+    }
+    const unsigned mh = wave_umin_u32(ah);
+    const unsigned ml = wave_umin_u32(ah == mh ? al : ~0u);
+    unsigned long long le_all = le, above = (static_cast<unsigned long long>(mh) << 32) | ml;  // padding counts as above
+    wg_combine2<NW>(le_all, above, [](unsigned long long p, unsigned long long q) { return p + q; },
+                    [](unsigned long long p, unsigned long long q) { return p < q ? p : q; }, cells, par);
+    const unsigned long long v2 = (static_cast<int64_t>(le_all) >= k1 + 2) ? v1 : above;
+    return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
+}
+
+template <int NT, int KPL>
+__global__ void __launch_bounds__(NT) k_universal_threshold_wg(const MedianArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ WgCells<NW> cells;
+    int par = 0;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const int64_t n = a.n;
+    const double* __restrict__ d = a.d1 + row * a.row_stride;
+    double v[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+        const int64_t i = static_cast<int64_t>(j) * NT + tid;
+        v[j] = i < n ? fabs(d[i]) : reg_pad();
+    }
+    const double median = wg_median<NW, KPL>(v, n, cells, par);
+    if (tid == 0) {
+        const double sigma = median / 0.6745;
+        a.thr_out[row] = sigma * a.sqrt_2_ln_n;
+    }
+}
+
 // rows of up to 64 * KPL samples: straight from global memory into registers, one wavefront per row
 template <int KPL>
 __global__ void __launch_bounds__(64) k_universal_threshold_reg(const MedianArgs a) {
@@ -553,17 +713,6 @@ __device__ __forceinline__ double denoiser_sigma_rule(int method, double sigma, 
         return sigma * (0.4745 + 0.1148 * log_n);
     }
     return sigma * sqrt(2.0 * log_n);
-}
-
-// Thresholding when coefficient and threshold are known to be finite and the threshold is not negative: the three
-// forms of apply_thr then agree, and soft thresholding is max(|c| - thr, 0) with the sign of c -- three instructions
-// instead of a dozen.  A coefficient that shrinks to zero may come out as -0.0 where apply_thr gives +0.0; callers use
-// this only where the value feeds an inverse cascade and nothing else: every reconstruction sum starts from +0.0,
-// (+0.0) + (-0.0) is +0.0 and a nonzero term is not changed by a zero of either sign, so the sign of a zero
-// coefficient cannot reach an output.
-__device__ __forceinline__ double shrink_finite(double c, double thr, bool soft) {
-    if (!soft) return (fabs(c) <= thr) ? 0.0 : c;
-    return __builtin_copysign(__builtin_fmax(fabs(c) - thr, 0.0), c);
 }
 
 struct RowDenoiseArgs {
@@ -1420,6 +1569,17 @@ struct DenoiserThrArgs {
 };
 
 constexpr int kThrChunk = 4096;  // doubles of a band staged in LDS at a time
+
+// UNIVERSAL and MINIMAX need nothing but sigma: one lane per (row, level)
+__global__ void __launch_bounds__(kThreads) k_denoiser_sigma_rules(const DenoiserThrArgs a) {
+    const int64_t id = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (id >= a.nrows * a.levels) return;
+    const int64_t row = id / a.levels;
+    const int level = static_cast<int>(id - row * a.levels) + 1;
+    double sigma = a.sigma[row];
+    if (a.level_scaled) sigma = sigma / sqrt(static_cast<double>(1 << (level - 1)));
+    a.thr[id] = denoiser_sigma_rule(a.method, sigma, a.n, a.log_n);
+}
 
 __global__ void __launch_bounds__(kThreads) k_denoiser_thresholds(const DenoiserThrArgs a) {
     __shared__ double stage[kThrChunk];

@@ -42,6 +42,8 @@ struct PlanOptions {
     int nt_stores = -1;                  // -1 by launch size, 0/1 forced
     int no_unroll = 0;                   // 1: generic tap loop also for 8+8-tap filters
     int no_reg_select = 0;               // 1: LDS/global selection kernels also for short rows
+    int select_lds_cap = 0;              // longest row the 256-lane selection kernel copies into LDS; 0 = default
+    int no_wg_select = 0;                // 1: rows of 2049..32768 samples through the 256-lane radix select, not the workgroup-resident descent
     int no_std_chains = 0;               // 1: plain reduction kernel for the streaming STD
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
     int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
@@ -187,6 +189,10 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_unroll = value != 0;
     } else if (strcmp(name, "no_reg_select") == 0) {
         o.no_reg_select = value != 0;
+    } else if (strcmp(name, "no_wg_select") == 0) {
+        o.no_wg_select = value != 0;
+    } else if (strcmp(name, "select_lds_cap") == 0) {
+        o.select_lds_cap = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_std_chains") == 0) {
         o.no_std_chains = value != 0;
     } else if (strcmp(name, "no_row_denoise") == 0) {
@@ -216,7 +222,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
+                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -474,7 +480,7 @@ static void scale_taps(const double* src, int len, double* dst) {
 
 // Streaming forward: split each row into runs of consecutive tiles, one workgroup per run.  Long runs
 // amortise the one halo a run pays for; short runs keep enough workgroups in flight when the batch
-// is small.  VW_FWD_CHUNKS caps the run length (1 = one tile per workgroup, as the halo kernels do).
+// is small.  Plan option fwd_chunks caps the run length (1 = one tile per workgroup, as the halo kernels do).
 static void plan_stream(const PlanOptions& opt, FwdArgs* a, int64_t rows, int lmax) {
     int off = 0;
     for (int j = a->lev0; j <= a->lev1; ++j) {
@@ -484,19 +490,23 @@ static void plan_stream(const PlanOptions& opt, FwdArgs* a, int64_t rows, int lm
         a->hlen[j] = static_cast<int32_t>(hl);
         off += static_cast<int>(hl);
     }
-    // runs of at most 6 tiles: whole-row runs are 3 % faster on some buffer placements and 6 % slower on
-    // others (every resident workgroup then sweeps its row in lockstep with all the others); 6 is steady
-    const int64_t cap = opt.fwd_chunks >= 1 ? opt.fwd_chunks : 6;
+    // Runs of at most 4 tiles, all of one length where the tile count allows.  How fast this launch streams depends
+    // on where the driver placed the buffers in physical memory (the same launch on the same rows takes 10.8 to
+    // 13.5 ms memory-bound, in four discrete steps, depending only on what was allocated before the coefficient
+    // block); long runs are the fastest on the best placement and the slowest on the worst (whole rows: 12.0 to
+    // 13.9 ms in the reference's arithmetic), runs of 4 stay within 12.4 to 12.7 ms on all of them.  A ragged last
+    // run costs more than a shorter run length (16 tiles as 5+5+5+1: 13.6 ms), hence the even deal.
+    const int64_t cap = opt.fwd_chunks >= 1 ? opt.fwd_chunks : 4;
     const int64_t tiles = a->tiles_per_row;
     const int64_t want_wgs = opt.stream_wgs >= 1 ? opt.stream_wgs : 16384;  // several rounds of resident workgroups on 256 CUs
     int64_t nseg = rows > 0 ? (want_wgs + rows - 1) / rows : 1;
-    if (nseg < 1) nseg = 1;
+    if (nseg < (tiles + cap - 1) / cap) nseg = (tiles + cap - 1) / cap;
     if (nseg > tiles) nseg = tiles;
-    int64_t nch = (tiles + nseg - 1) / nseg;
-    if (nch > cap) nch = cap;
-    if (nch < 1) nch = 1;
-    a->nchunks = static_cast<int32_t>(nch);
-    a->ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
+    if (nseg < 1) nseg = 1;
+    a->ntiles = static_cast<int32_t>(nseg);
+    a->run_base = static_cast<int32_t>(tiles / nseg);
+    a->run_rem = static_cast<int32_t>(tiles % nseg);
+    a->nchunks = a->run_base + (a->run_rem > 0 ? 1 : 0);
 }
 
 // Long-context streaming (k_fwd_sdry / k_inv_sdry): shape 1 = 512 lanes, 2048-sample tiles, histories up to 2046
@@ -744,6 +754,8 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             a.ntiles = static_cast<int32_t>((n + T - 1) / T);
             a.tiles_per_row = a.ntiles;
             a.nchunks = 1;
+            a.run_base = 1;
+            a.run_rem = 0;
             a.lev0 = st.lev0;
             a.lev1 = st.lev1;
             a.lh = lh;
@@ -1297,7 +1309,29 @@ static void launch_universal_threshold(const vw_ctx* ctx, const MedianArgs& a, i
         case 32: hipLaunchKernelGGL(k_universal_threshold_reg<32>, grid, dim3(64), 0, s, a); return;
         default: break;
     }
-    hipLaunchKernelGGL(k_universal_threshold<kThreads>, grid, dim3(kThreads), lds, s, a);
+    if (!ctx->opt.no_wg_select && n > 2048 && n <= 32768) {
+        // the row in the registers of one workgroup, read from HBM once
+        if (n <= 4096)
+            hipLaunchKernelGGL((k_universal_threshold_wg<256, 16>), grid, dim3(256), 0, s, a);
+        else if (n <= 8192)
+            hipLaunchKernelGGL((k_universal_threshold_wg<1024, 8>), grid, dim3(1024), 0, s, a);
+        else if (n <= 16384)
+            hipLaunchKernelGGL((k_universal_threshold_wg<1024, 16>), grid, dim3(1024), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_universal_threshold_wg<1024, 32>), grid, dim3(1024), 0, s, a);
+        return;
+    }
+    (void)launch_tile_nt(k_universal_threshold<kThreads>, a, kThreads, b, lds, s);
+}
+
+// Longest row the 256-lane selection kernel copies into LDS, so that the nine passes of the radix select never leave
+// the CU: whatever one workgroup can have beside the kernel's static 1.1 KiB (18432 samples = 144 KiB on gfx950).  Rows
+// of 16384 samples took 3.07 ms per 16384 rows reading global memory nine times.
+static int select_lds_cap(const vw_ctx* ctx) {
+    int cap = (ctx->lds_limit - 16384) / 8;
+    if (cap < 4096) cap = 4096;
+    if (ctx->opt.select_lds_cap > 0 && ctx->opt.select_lds_cap < cap) cap = ctx->opt.select_lds_cap;
+    return cap;
 }
 
 static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels,
@@ -1309,8 +1343,7 @@ static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     a.nrows = b;
     a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
     a.thr_out = thr;
-    // rows up to 4096 samples are copied to LDS (32 KiB) so that the nine passes never leave the CU
-    a.lds_cap = 4096;
+    a.lds_cap = select_lds_cap(ctx);
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
     if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
     launch_universal_threshold(ctx, a, b, n, lds, s);
@@ -1359,7 +1392,7 @@ extern "C" int32_t vw_swt_universal_threshold_batch(vw_ctx* ctx, const double* c
     a.nrows = b;
     a.sqrt_2_ln_n = sqrt_2_ln_n < 0 ? host_sqrt_2_ln_n(n) : sqrt_2_ln_n;
     a.thr_out = t;
-    a.lds_cap = 4096;
+    a.lds_cap = select_lds_cap(ctx);
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
     launch_universal_threshold(ctx, a, b, n, lds, ctx->stream);
     VW_HIP(ctx, hipGetLastError());
@@ -1675,6 +1708,8 @@ static int denoiser_thresholds_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
     if (method == VW_THRESHOLD_BAYES)
         hipLaunchKernelGGL(k_denoiser_bayes, dim3(static_cast<unsigned>((nblocks + kChainRows - 1) / kChainRows)), dim3(64), 0, s, a);
+    else if (method == VW_THRESHOLD_UNIVERSAL || method == VW_THRESHOLD_MINIMAX)
+        hipLaunchKernelGGL(k_denoiser_sigma_rules, dim3(static_cast<unsigned>((nblocks + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
     else
         hipLaunchKernelGGL(k_denoiser_thresholds, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, s, a);
     VW_HIP(ctx, hipGetLastError());

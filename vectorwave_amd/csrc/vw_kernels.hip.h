@@ -55,6 +55,9 @@ struct FwdArgs {
     // streaming kernel only: a workgroup walks `nchunks` consecutive tiles of its row and carries the
     // last hlen[j] samples of V_{j-1} (the left context level j needs) from tile to tile in LDS
     int32_t tiles_per_row, nchunks;
+    // k_fwd_stream only: the row's tiles are dealt evenly over its `ntiles` runs: run_base tiles each, one more in
+    // the first run_rem runs (a short last run would pay a whole halo for little work and end early)
+    int32_t run_base, run_rem;
     int32_t hoff[kMaxLevels + 2], hlen[kMaxLevels + 2];
     int32_t ndry, hist_cap;  // k_fwd_sdry: warm-up tiles per run, doubles of history storage
     unsigned long long* first_bad;   // nullptr = no finite check
@@ -160,6 +163,21 @@ __device__ __forceinline__ double2 gload_pair(const double* __restrict__ row, in
     return x;
 }
 __device__ __forceinline__ int64_t mod_wrap(int64_t i, int64_t n);
+
+// One double from a wave-uniform address through the scalar unit.  As a vector load the value would sit behind
+// every older vector-memory request of the wave (the counter retires in order), so waiting for it also drains
+// the prefetched bands -- the LDS-DMA ring would lose its two levels of run-ahead to one threshold per level.
+// Read only: written by an earlier kernel.
+__device__ __forceinline__ double uniform_load_f64(const double* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    // (the builtin returns int: without the casts the low word would be sign-extended over the high one)
+    const uint32_t uhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u >> 32)));
+    const uint32_t ulo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(u & 0xffffffffu)));
+    const uint64_t su = (static_cast<uint64_t>(uhi) << 32) | static_cast<uint64_t>(ulo);
+    double v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(su) : "memory");
+    return v;
+}
 template <int VM>
 __device__ __forceinline__ double2 gload_pair_wrapped(const double* __restrict__ row, int64_t t, int64_t n) {  // any t, periodic
     double2 x;
@@ -235,6 +253,17 @@ __device__ __forceinline__ double apply_thr(double c, double thr, int mode) {
     const double m = a - thr;
     // signum(c) * m with signum in {+1, -1, +-0, NaN}
     return c > 0.0 ? m : (c < 0.0 ? -m : c * m);
+}
+
+// Thresholding when coefficient and threshold are known to be finite and the threshold is not negative: the three
+// forms of apply_thr then agree, and soft thresholding is max(|c| - thr, 0) with the sign of c -- three instructions
+// instead of a dozen.  A coefficient that shrinks to zero may come out as -0.0 where apply_thr gives +0.0; callers use
+// this only where the value feeds an inverse cascade and nothing else: every reconstruction sum starts from +0.0,
+// (+0.0) + (-0.0) is +0.0 and a nonzero term is not changed by a zero of either sign, so the sign of a zero
+// coefficient cannot reach an output.
+__device__ __forceinline__ double shrink_finite(double c, double thr, bool soft) {
+    if (!soft) return (fabs(c) <= thr) ? 0.0 : c;
+    return __builtin_copysign(__builtin_fmax(fabs(c) - thr, 0.0), c);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,9 +596,8 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
     const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t row = id / a.ntiles;
     const int seg = static_cast<int>(id - row * a.ntiles);
-    const int tile0 = seg * a.nchunks;
-    int ntl = a.tiles_per_row - tile0;
-    if (ntl > a.nchunks) ntl = a.nchunks;
+    const int tile0 = seg * a.run_base + (seg < a.run_rem ? seg : a.run_rem);
+    const int ntl = a.run_base + (seg < a.run_rem ? 1 : 0);
     const int64_t n = a.n;
     const int64_t ns = a.n_store;
     const double* __restrict__ inrow = a.in + row * a.in_stride;
@@ -1028,7 +1056,7 @@ __global__ void __launch_bounds__(kThreads) k_inv_fused(const InvArgs a) {
 
     for (int j = a.lev1; j >= a.lev0; --j) {
         const int s = 1 << (j - 1);
-        const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+        const double thr = (a.thr_mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
         // publish W_j (thresholded on the way in when denoising)
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
@@ -1330,7 +1358,7 @@ __global__ void __launch_bounds__(kThreads, 4) k_inv_blk(const InvArgs a) {
 
     for (int j = a.lev1; j >= a.lev0; --j) {
         const int S = j - 2;
-        const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+        const double thr = (a.thr_mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
         // publish W_j (thresholded on the way in when denoising) in this level's layout
         {
             const int base = (blk_slot_rt(tid, S) << 4) + kBlkWOff;
@@ -1446,7 +1474,8 @@ __global__ void __launch_bounds__(kThreads, 4) k_inv_blk(const InvArgs a) {
 // needs are filled from a clamped address (valid memory, values never used).  Bands travel by slot j % 3.
 //
 // PLAIN = false adds a pass over the freshly landed slots of the wave (threshold-on-load for the denoisers,
-// band mask, finite check) and makes every wait a full drain; the plain form runs that pass only on the
+// band mask, finite check): it touches only W_j (and R on the first level), which the counted wait of the level
+// covers, so the two younger bands stay in flight across it; the plain form runs that pass only on the
 // ZERO_PADDING tiles that reach beyond their row (zeros right of the signal).
 // Needs 16-byte-aligned rows with even n >= 2560 (one wrap at most inside a tile's halo).
 
@@ -1562,9 +1591,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
             ring_issue<MODE>(wbase + static_cast<int64_t>(j - 3) * a.w_band_stride, lds_base, (1 + (j - 2) % 3) * kRingBand, j - 4,
                              a.pend[j - 2] >> 1, t0, n, wave, lane, redge);
         // everything older than the two youngest bands has landed: R (first pass) and W_j
-        if (!PLAIN) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (j - 2 >= a.lev0) {
+        if (j - 2 >= a.lev0) {
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         } else if (j - 1 >= a.lev0) {
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -1572,41 +1599,67 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (!PLAIN || edge) {
-            // pass over the slots this wave has filled: W_j (and R on the first level)
-            const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+            // pass over the slots this wave has filled: W_j (and R on the first level).  Kept lean -- it runs once per
+            // level on 5 slots per lane: finite values under a finite non-negative threshold take the three-instruction
+            // form of the thresholding rule (a wave-uniform choice), and the non-finite report, which needs 64-bit
+            // index arithmetic and atomics, is a second loop that only a wave holding such a value enters.
+            const int mode = a.thr_mode;
+            const double thr = (mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
+            const bool thr_plain = finite_f64(thr) && thr >= 0.0;
             const bool use_w = (a.band_mask >> (j - 1)) & 1u;
             const bool use_r = (a.band_mask >> 31) & 1u;
             const int wofs = (1 + j % 3) * kRingBand;
             const int pl = a.pend[j] >> 1;
+            const bool top = (j == a.lev1);
+            bool bad = false;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int slot = 64 * (wave + 4 * i) + lane;
                 const int pair = blk_slot_rt(slot, S);
-                const int64_t t = t0 + 2 * pair;
-                const bool inrow = (MODE == kPeriodic) || (t < n);
+                const bool inrow = (MODE == kPeriodic) || (t0 + 2 * pair < n);
+                const bool live = inrow && pair < pl;
                 double2* pw = reinterpret_cast<double2*>(lds + wofs + 16 * slot);
                 double2 w = *pw;
-                if (!use_w || !inrow || pair >= pl) w = make_double2(0.0, 0.0);
-                if (a.thr_mode != 0) {
-                    w.x = apply_thr(w.x, thr, a.thr_mode);
-                    w.y = apply_thr(w.y, thr, a.thr_mode);
+                if (!use_w || !live) w = make_double2(0.0, 0.0);
+                bool nonfin = !finite_f64(w.x) || !finite_f64(w.y);
+                if (mode != 0) {
+                    if (thr_plain && __builtin_amdgcn_ballot_w64(nonfin) == 0) {
+                        w.x = shrink_finite(w.x, thr, mode != 2);
+                        w.y = shrink_finite(w.y, thr, mode != 2);
+                    } else {
+                        w.x = apply_thr(w.x, thr, mode);
+                        w.y = apply_thr(w.y, thr, mode);
+                        nonfin = !finite_f64(w.x) || !finite_f64(w.y);
+                    }
                 }
-                if (a.first_bad != nullptr && pair < kThreads * PPT && t < n) {
+                bad = bad || nonfin;
+                *pw = w;
+                if (top) {
+                    double2* pr = reinterpret_cast<double2*>(lds + 16 * slot);
+                    double2 r = *pr;
+                    if (!use_r || !live) r = make_double2(0.0, 0.0);
+                    bad = bad || !finite_f64(r.x) || !finite_f64(r.y);
+                    *pr = r;
+                }
+            }
+            if (a.first_bad != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0) {
+                // the wave holds a NaN or an infinity: report the first one of the tile proper by its flat index
+#pragma unroll 1
+                for (int i = 0; i < 4; ++i) {  // the fifth block of a wave is halo: pairs >= kThreads * PPT
+                    const int slot = 64 * (wave + 4 * i) + lane;
+                    const int pair = blk_slot_rt(slot, S);
+                    const int64_t t = t0 + 2 * pair;
+                    if (pair >= kThreads * PPT || t >= n) continue;
+                    const double2 w = *reinterpret_cast<const double2*>(lds + wofs + 16 * slot);
                     const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(j - 1) * a.w_band_stride;
                     if (!finite_f64(w.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
                     if (!finite_f64(w.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
-                }
-                *pw = w;
-                if (j == a.lev1) {
-                    double2* pr = reinterpret_cast<double2*>(lds + 16 * slot);
-                    double2 r = *pr;
-                    if (!use_r || !inrow || pair >= pl) r = make_double2(0.0, 0.0);
-                    if (a.first_bad != nullptr && a.check_rin && pair < kThreads * PPT && t < n) {
-                        const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
-                        if (!finite_f64(r.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t));
-                        if (!finite_f64(r.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
+                    if (top && a.check_rin) {
+                        const double2 r = *reinterpret_cast<const double2*>(lds + 16 * slot);
+                        const int64_t flat1 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
+                        if (!finite_f64(r.x)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat1 + t));
+                        if (!finite_f64(r.y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat1 + t + 1));
                     }
-                    *pr = r;
                 }
             }
         }
@@ -1863,7 +1916,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_carry(const InvArgs a) {
             const int wofs = (1 + j % 3) * kRingBand;
             if (!PLAIN || edge) {
                 // pass over the slots this wave has filled: W_j (and R on the first level)
-                const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+                const double thr = (a.thr_mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
                 const bool use_w = (a.band_mask >> (j - 1)) & 1u;
                 const bool use_r = (a.band_mask >> 31) & 1u;
                 const int pl = pairs_of(j);
@@ -2076,7 +2129,7 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
 
         for (int j = a.lev1; j >= a.lev0; --j) {
             const int s = 1 << (j - 1);
-            const double thr = (a.thr_mode != 0) ? a.thr[row * a.thr_row_stride + (j - 1) * a.thr_level_stride] : 0.0;
+            const double thr = (a.thr_mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
             // ---- publish W_j (thresholded on the way in when denoising) ---------------
 #pragma unroll
             for (int c = 0; c < PPT; ++c) {
