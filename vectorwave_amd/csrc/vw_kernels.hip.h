@@ -1611,33 +1611,59 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
             const int wofs = (1 + j % 3) * kRingBand;
             const int pl = a.pend[j] >> 1;
             const bool top = (j == a.lev1);
+            // all five slots are requested before the first is used; the decisions that do not depend on the slot are
+            // taken once per level, outside the loops
+            double2 wv[5];
+            double2* pw[5];
+            bool live[5];
             bool bad = false;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int slot = 64 * (wave + 4 * i) + lane;
                 const int pair = blk_slot_rt(slot, S);
                 const bool inrow = (MODE == kPeriodic) || (t0 + 2 * pair < n);
-                const bool live = inrow && pair < pl;
-                double2* pw = reinterpret_cast<double2*>(lds + wofs + 16 * slot);
-                double2 w = *pw;
-                if (!use_w || !live) w = make_double2(0.0, 0.0);
-                bool nonfin = !finite_f64(w.x) || !finite_f64(w.y);
-                if (mode != 0) {
-                    if (thr_plain && __builtin_amdgcn_ballot_w64(nonfin) == 0) {
-                        w.x = shrink_finite(w.x, thr, mode != 2);
-                        w.y = shrink_finite(w.y, thr, mode != 2);
+                live[i] = inrow && pair < pl;
+                pw[i] = reinterpret_cast<double2*>(lds + wofs + 16 * slot);
+                wv[i] = *pw[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (!use_w || !live[i]) wv[i] = make_double2(0.0, 0.0);
+                bad = bad || !finite_f64(wv[i].x) || !finite_f64(wv[i].y);
+            }
+            if (mode != 0) {
+                if (thr_plain && __builtin_amdgcn_ballot_w64(bad) == 0) {
+                    if (mode != 2) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            wv[i].x = shrink_finite(wv[i].x, thr, true);
+                            wv[i].y = shrink_finite(wv[i].y, thr, true);
+                        }
                     } else {
-                        w.x = apply_thr(w.x, thr, mode);
-                        w.y = apply_thr(w.y, thr, mode);
-                        nonfin = !finite_f64(w.x) || !finite_f64(w.y);
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            wv[i].x = shrink_finite(wv[i].x, thr, false);
+                            wv[i].y = shrink_finite(wv[i].y, thr, false);
+                        }
+                    }
+                } else {
+                    bad = false;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {  // (a rolled loop would index wv dynamically and put it into scratch)
+                        wv[i].x = apply_thr(wv[i].x, thr, mode);
+                        wv[i].y = apply_thr(wv[i].y, thr, mode);
+                        bad = bad || !finite_f64(wv[i].x) || !finite_f64(wv[i].y);
                     }
                 }
-                bad = bad || nonfin;
-                *pw = w;
-                if (top) {
-                    double2* pr = reinterpret_cast<double2*>(lds + 16 * slot);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) *pw[i] = wv[i];
+            if (top) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    double2* pr = reinterpret_cast<double2*>(reinterpret_cast<char*>(pw[i]) - wofs);
                     double2 r = *pr;
-                    if (!use_r || !live) r = make_double2(0.0, 0.0);
+                    if (!use_r || !live[i]) r = make_double2(0.0, 0.0);
                     bad = bad || !finite_f64(r.x) || !finite_f64(r.y);
                     *pr = r;
                 }
