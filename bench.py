@@ -27,7 +27,8 @@ Prints ONE JSON line (rank 0).  Fields beyond the driver contract:
                   bounded sample of the same workload on this host's cores: the
                   per-signal scalar path (OpenMP over signals) and, as
                   `cpu_baseline_soa`, the reference's SIMD batch scheme
-                  (structure-of-arrays, lanes along the batch).  Reported, not targets.
+                  (structure-of-arrays, lanes along the batch).  Reported, not targets; single-GPU
+                  runs only.
 """
 import argparse
 import ctypes as C
@@ -376,7 +377,8 @@ def main():
                          "pct_of_hbm_roofline": round(100.0 * o_val / world * 16 * (J + 2) / HBM_PEAK_GBS, 2)}
         state["rows"] = rows_main
 
-    if rank == 0 and not args.no_cpu_baseline:
+    # the CPU legs run beside the single-GPU line only: with more ranks the other processes would sit waiting for rank 0
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, cpu_soa = cpu_baseline(o, w, J, n, args)
 
     samples = rows_total * n * args.steps
