@@ -511,53 +511,60 @@ __global__ void __launch_bounds__(NT) k_universal_threshold(const MedianArgs a) 
 // rows of up to NT * KPL samples in the registers of one workgroup (NT = 256 or 1024 lanes)
 // ---------------------------------------------------------------------------
 //
-// The threshold-count descent of reg_select with the count of a step summed over the waves of the workgroup:
-// every wave counts its keys below the threshold with ballots (a scalar per wave), lane 0 puts it into the wave's
-// LDS cell, one barrier, every lane adds up the cells.  The cells are double-buffered by the parity of the step,
-// so a step needs one barrier: a wave can only overwrite a buffer after the barrier of the step in between, which
-// every wave reaches after it has read that buffer.  The row is read from HBM exactly once (the 256-lane radix
-// select reads a row longer than its LDS stage nine times, and its LDS histogram serialises on the one bin that
-// nearly all keys of a band share in the high-order passes: 3.07 ms for 16384 rows of 16384 samples).
-template <int NW>
+// The threshold-count descent of reg_select with the counts of a step summed over the waves of the workgroup: every
+// wave counts its keys below the thresholds with ballots (scalars per wave) and the counts meet in LDS.  The row is
+// read from HBM exactly once (the 256-lane radix select reads a row longer than its LDS stage nine times, and its LDS
+// histogram serialises on the one bin that nearly all keys of a band share in the high-order passes: 3.07 ms for
+// 16384 rows of 16384 samples).
+// Exchange cells: one per combine, used once, zero when the kernel starts (k_universal_threshold_wg clears them), so no
+// cell is ever reset and a combine needs one barrier.  Lane 0 of every wave folds the wave's value into the cell with
+// an LDS atomic (add, or, max), and after the barrier every lane reads the one result -- summing sixteen per-wave cells
+// in every lane cost more instructions than the compares of a step.  AND and MIN go through OR and MAX of the
+// complement.
+constexpr int kWgCells = 80;  // 2 (range) + 2 * 32 (two-bit steps) + 1 (odd last bit) + 1 (last key) + 2 (second order statistic)
 struct WgCells {
-    unsigned long long x[2][NW];
-    unsigned long long y[2][NW];
+    unsigned long long c[kWgCells];
 };
 
-template <int NW, class FX, class FY>
-__device__ __forceinline__ void wg_combine2(unsigned long long& x, unsigned long long& y, FX fx, FY fy, WgCells<NW>& c, int& par) {
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        c.x[par][wave] = x;
-        c.y[par][wave] = y;
-    }
-    __syncthreads();
-    unsigned long long rx = c.x[par][0], ry = c.y[par][0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) {
-        rx = fx(rx, c.x[par][w]);
-        ry = fy(ry, c.y[par][w]);
-    }
-    x = rx;
-    y = ry;
-    par ^= 1;
+enum WgOp { kWgAdd, kWgOr, kWgAnd, kWgMin };
+
+template <WgOp OP>
+__device__ __forceinline__ void wg_fold(unsigned long long* cell, unsigned long long x) {
+    if (OP == kWgAdd) atomicAdd(cell, x);
+    if (OP == kWgOr) atomicOr(cell, x);
+    if (OP == kWgAnd) atomicOr(cell, ~x);
+    if (OP == kWgMin) atomicMax(cell, ~x);
+}
+template <WgOp OP>
+__device__ __forceinline__ unsigned long long wg_unfold(unsigned long long r) {
+    return (OP == kWgAnd || OP == kWgMin) ? ~r : r;
 }
 
-template <int NW, class FX>
-__device__ __forceinline__ unsigned long long wg_combine1(unsigned long long x, FX fx, WgCells<NW>& c, int& par) {
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) c.x[par][wave] = x;
+// x and y are wave-uniform; every lane of the workgroup gets the combined values
+template <WgOp OPX, WgOp OPY>
+__device__ __forceinline__ void wg_combine2(unsigned long long& x, unsigned long long& y, WgCells& c, int& idx) {
+    if ((threadIdx.x & 63) == 0) {
+        wg_fold<OPX>(&c.c[idx], x);
+        wg_fold<OPY>(&c.c[idx + 1], y);
+    }
     __syncthreads();
-    unsigned long long rx = c.x[par][0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) rx = fx(rx, c.x[par][w]);
-    par ^= 1;
-    return rx;
+    x = wg_unfold<OPX>(c.c[idx]);
+    y = wg_unfold<OPY>(c.c[idx + 1]);
+    idx += 2;
+}
+
+template <WgOp OP>
+__device__ __forceinline__ unsigned long long wg_combine1(unsigned long long x, WgCells& c, int& idx) {
+    if ((threadIdx.x & 63) == 0) wg_fold<OP>(&c.c[idx], x);
+    __syncthreads();
+    const unsigned long long r = wg_unfold<OP>(c.c[idx]);
+    idx += 1;
+    return r;
 }
 
 // the key of rank k (0-based) among the n keys of the row held by the whole workgroup (padding = reg_pad())
 template <int NW, int KPL>
-__device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], int64_t n, int64_t k, WgCells<NW>& cells, int& par) {
+__device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], int64_t n, int64_t k, WgCells& cells, int& par) {
     unsigned ah = ~0u, al = ~0u, oh = 0u, ol = 0u;
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
@@ -570,8 +577,7 @@ __device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], 
     }
     unsigned long long all_and = (static_cast<unsigned long long>(wave_and_u32(ah)) << 32) | wave_and_u32(al);
     unsigned long long all_or = (static_cast<unsigned long long>(wave_or_u32(oh)) << 32) | wave_or_u32(ol);
-    wg_combine2<NW>(all_and, all_or, [](unsigned long long p, unsigned long long q) { return p & q; },
-                    [](unsigned long long p, unsigned long long q) { return p | q; }, cells, par);
+    wg_combine2<kWgAnd, kWgOr>(all_and, all_or, cells, par);
     const unsigned long long diff = all_and ^ all_or;
     if (diff == 0) return all_and;  // every key is the same
     int pos = 64 - __clzll(static_cast<long long>(diff));  // bits [0, pos) are undecided
@@ -579,13 +585,50 @@ __device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], 
     unsigned below = 0;
     unsigned in_range = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(n)));
     const unsigned kk = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(k)));
+    // two bits per step while two are left: three thresholds, their three counts through ONE exchange (the exchange and
+    // its barrier over up to sixteen waves cost more than the compares, so halving the steps pays here; in the
+    // single-wave descent of reg_select it does not)
+#pragma unroll 1
+    while (pos > 1 && in_range > 1) {
+        pos -= 2;
+        const unsigned long long q1 = 1ull << pos;
+        const unsigned long long t1 = prefix | q1, t2 = prefix | (q1 << 1), t3 = prefix | (q1 * 3);
+        unsigned w1, w2, w3;
+        if (pos >= 32) {
+            w1 = count_below<KPL, true>(v, t1);
+            w2 = count_below<KPL, true>(v, t2);
+            w3 = count_below<KPL, true>(v, t3);
+        } else {
+            w1 = count_below<KPL, false>(v, t1);
+            w2 = count_below<KPL, false>(v, t2);
+            w3 = count_below<KPL, false>(v, t3);
+        }
+        unsigned long long x = (static_cast<unsigned long long>(w2) << 32) | w1, y = w3;  // n <= 32768: no carry between the halves
+        wg_combine2<kWgAdd, kWgAdd>(x, y, cells, par);
+        const unsigned c1 = static_cast<unsigned>(x), c2 = static_cast<unsigned>(x >> 32), c3 = static_cast<unsigned>(y);
+        const unsigned end = below + in_range;  // keys below the end of the current range
+        if (kk < c1) {
+            in_range = c1 - below;
+        } else if (kk < c2) {
+            prefix = t1;
+            in_range = c2 - c1;
+            below = c1;
+        } else if (kk < c3) {
+            prefix = t2;
+            in_range = c3 - c2;
+            below = c2;
+        } else {
+            prefix = t3;
+            in_range = end - c3;
+            below = c3;
+        }
+    }
 #pragma unroll 1
     while (pos > 0 && in_range > 1) {
         --pos;
         const unsigned long long t = prefix | (1ull << pos);
         const unsigned cw = (pos >= 32) ? count_below<KPL, true>(v, t) : count_below<KPL, false>(v, t);
-        const unsigned c1 = static_cast<unsigned>(
-            wg_combine1<NW>(cw, [](unsigned long long p, unsigned long long q) { return p + q; }, cells, par));
+        const unsigned c1 = static_cast<unsigned>(wg_combine1<kWgAdd>(cw, cells, par));
         if (kk < c1) {
             in_range = c1 - below;
         } else {
@@ -614,11 +657,11 @@ __device__ __forceinline__ unsigned long long wg_select(const double (&v)[KPL], 
         const int src = __builtin_ctzll(who);
         found = (static_cast<unsigned long long>(lane_u32(fh, src)) << 32) | lane_u32(fl, src);
     }
-    return wg_combine1<NW>(found, [](unsigned long long p, unsigned long long q) { return p < q ? p : q; }, cells, par);
+    return wg_combine1<kWgMin>(found, cells, par);
 }
 
 template <int NW, int KPL>
-__device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, WgCells<NW>& cells, int& par) {
+__device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, WgCells& cells, int& par) {
     const int64_t k1 = (n % 2 == 0) ? n / 2 - 1 : n / 2;
     const unsigned long long v1 = wg_select<NW, KPL>(v, n, k1, cells, par);
     if (n % 2 != 0) return __longlong_as_double(static_cast<long long>(v1));
@@ -639,8 +682,7 @@ __device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, W
     const unsigned mh = wave_umin_u32(ah);
     const unsigned ml = wave_umin_u32(ah == mh ? al : ~0u);
     unsigned long long le_all = le, above = (static_cast<unsigned long long>(mh) << 32) | ml;  // padding counts as above
-    wg_combine2<NW>(le_all, above, [](unsigned long long p, unsigned long long q) { return p + q; },
-                    [](unsigned long long p, unsigned long long q) { return p < q ? p : q; }, cells, par);
+    wg_combine2<kWgAdd, kWgMin>(le_all, above, cells, par);
     const unsigned long long v2 = (static_cast<int64_t>(le_all) >= k1 + 2) ? v1 : above;
     return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
 }
@@ -648,9 +690,11 @@ __device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, W
 template <int NT, int KPL>
 __global__ void __launch_bounds__(NT) k_universal_threshold_wg(const MedianArgs a) {
     constexpr int NW = NT / 64;
-    __shared__ WgCells<NW> cells;
-    int par = 0;
+    __shared__ WgCells cells;
+    int par = 0;  // next unused exchange cell
     const int tid = threadIdx.x;
+    if (tid < kWgCells) cells.c[tid] = 0ull;
+    __syncthreads();
     const int64_t row = blockIdx.x;
     const int64_t n = a.n;
     const double* __restrict__ d = a.d1 + row * a.row_stride;
