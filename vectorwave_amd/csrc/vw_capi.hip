@@ -1300,13 +1300,13 @@ static int reg_kpl(const PlanOptions& opt, int64_t n) {
     return 0;
 }
 
-static void launch_universal_threshold(const vw_ctx* ctx, const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
+static hipError_t launch_universal_threshold(const vw_ctx* ctx, const MedianArgs& a, int64_t b, int64_t n, size_t lds, hipStream_t s) {
     const dim3 grid(static_cast<unsigned>(b));
     switch (reg_kpl(ctx->opt, n)) {
-        case 4: hipLaunchKernelGGL(k_universal_threshold_reg<4>, grid, dim3(64), 0, s, a); return;
-        case 8: hipLaunchKernelGGL(k_universal_threshold_reg<8>, grid, dim3(64), 0, s, a); return;
-        case 16: hipLaunchKernelGGL(k_universal_threshold_reg<16>, grid, dim3(64), 0, s, a); return;
-        case 32: hipLaunchKernelGGL(k_universal_threshold_reg<32>, grid, dim3(64), 0, s, a); return;
+        case 4: hipLaunchKernelGGL(k_universal_threshold_reg<4>, grid, dim3(64), 0, s, a); return hipGetLastError();
+        case 8: hipLaunchKernelGGL(k_universal_threshold_reg<8>, grid, dim3(64), 0, s, a); return hipGetLastError();
+        case 16: hipLaunchKernelGGL(k_universal_threshold_reg<16>, grid, dim3(64), 0, s, a); return hipGetLastError();
+        case 32: hipLaunchKernelGGL(k_universal_threshold_reg<32>, grid, dim3(64), 0, s, a); return hipGetLastError();
         default: break;
     }
     if (!ctx->opt.no_wg_select && n > 2048 && n <= 32768) {
@@ -1319,9 +1319,9 @@ static void launch_universal_threshold(const vw_ctx* ctx, const MedianArgs& a, i
             hipLaunchKernelGGL((k_universal_threshold_wg<1024, 16>), grid, dim3(1024), 0, s, a);
         else
             hipLaunchKernelGGL((k_universal_threshold_wg<1024, 32>), grid, dim3(1024), 0, s, a);
-        return;
+        return hipGetLastError();
     }
-    (void)launch_tile_nt(k_universal_threshold<kThreads>, a, kThreads, b, lds, s);
+    return launch_tile_nt(k_universal_threshold<kThreads>, a, kThreads, b, lds, s);  // also reports a refused LDS size
 }
 
 // Longest row the 256-lane selection kernel copies into LDS, so that the nine passes of the radix select never leave
@@ -1346,8 +1346,7 @@ static int universal_threshold_dev(vw_ctx* ctx, const double* coeffs, int64_t b,
     a.lds_cap = select_lds_cap(ctx);
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
     if (b > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-    launch_universal_threshold(ctx, a, b, n, lds, s);
-    VW_HIP(ctx, hipGetLastError());
+    VW_HIP(ctx, launch_universal_threshold(ctx, a, b, n, lds, s));
     return VW_OK;
 }
 
@@ -1394,8 +1393,7 @@ extern "C" int32_t vw_swt_universal_threshold_batch(vw_ctx* ctx, const double* c
     a.thr_out = t;
     a.lds_cap = select_lds_cap(ctx);
     const size_t lds = (n <= a.lds_cap) ? static_cast<size_t>((n + 1) & ~static_cast<int64_t>(1)) * 8 : 16;
-    launch_universal_threshold(ctx, a, b, n, lds, ctx->stream);
-    VW_HIP(ctx, hipGetLastError());
+    VW_HIP(ctx, launch_universal_threshold(ctx, a, b, n, lds, ctx->stream));
     VW_HIP(ctx, hipMemcpyAsync(thresholds, t, static_cast<size_t>(b) * 8, hipMemcpyDeviceToHost, ctx->stream));
     VW_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VW_OK;
