@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times every BASELINE configuration on one GPU through the device-pointer C ABI (inputs resident in
 HBM, HIP events on the launch stream) and prints one JSON object.  Not the headline bench (bench.py is);
-this is the per-configuration table quoted in DESIGN.md.
+this is the per-configuration table of the design notes.
 
 usage: python tools/bench_configs.py [--steps K] [--warmup W] [--out file.json]
 """
