@@ -52,14 +52,16 @@ def test_wavelet_operations_threshold_nan(ctx, soft):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [777, 4096, 5120])
 @pytest.mark.parametrize("mode", [P, Z])
 @pytest.mark.parametrize("soft", [True, False])
-def test_denoise_fixed_nan_threshold(ctx, mode, soft):
+def test_denoise_fixed_nan_threshold(ctx, mode, soft, n):
     """WaveletDenoiser.denoiseFixed(x, NaN, type): soft propagates NaN into every output sample, hard keeps every
-    coefficient (denoising/WaveletDenoiser.java:350-360)."""
+    coefficient (denoising/WaveletDenoiser.java:350-360).  Rows of 4096 and 5120 samples take the tile kernels that
+    threshold the detail operands as the inverse consumes them."""
     import torch
     w = get_wavelet("db4")
-    x = signals(3, 777, seed=8)
+    x = signals(3, n, seed=8)
     st, want, _ = o.wavelet_denoise_batch(x, w, 0, o.FIXED, soft, mode, fixed_threshold=float("nan"))
     assert st == 0
     got, _ = dev_wavelet_denoise(ctx, torch.from_numpy(x).cuda(), "db4", 0, mode, N.VW_THRESHOLD_FIXED, soft,
@@ -72,14 +74,20 @@ def test_denoise_fixed_nan_threshold(ctx, mode, soft):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1000, 4096, 5120])
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("thr", [float("nan"), float("inf"), 0.0, 0.25])
 @pytest.mark.parametrize("soft", [True, False])
-def test_swt_adapter_nan_threshold(ctx, soft):
+def test_swt_adapter_nan_threshold(ctx, soft, thr, mode, n):
     """VectorWaveSwtAdapter.denoise(x, J, NaN, soft): `NaN < 0` is false, so NaN is used as a fixed threshold through
-    MutableMultiLevelMODWTResult.applyThreshold: soft zeroes every detail, hard keeps them."""
+    MutableMultiLevelMODWTResult.applyThreshold: soft zeroes every detail, hard keeps them.  An infinite threshold
+    zeroes every detail under both rules, a zero threshold keeps them; rows of 4096 and 5120 samples take the tile
+    kernels that threshold the detail operands as the inverse consumes them (a threshold that is no finite
+    non-negative number goes through their general rule)."""
     w = get_wavelet("db4")
-    x = signals(2, 1000, seed=2)
-    st, want = o.swt_denoise_batch(x, w, 3, float("nan"), soft, P)
+    x = signals(2, n, seed=2)
+    st, want = o.swt_denoise_batch(x, w, 3, thr, soft, mode)
     assert st == 0 and not np.any(np.isnan(want))
-    st, got, _ = gpu_denoise(ctx, x, "db4", 3, P, float("nan"), soft)
+    st, got, _ = gpu_denoise(ctx, x, "db4", 3, mode, thr, soft)
     assert st == N.VW_OK, ctx.last_error()
-    assert_bits_equal(got, want, "swt denoise with a NaN threshold, soft=%s" % soft)
+    assert_bits_equal(got, want, "swt denoise with threshold %r, soft=%s" % (thr, soft))

@@ -1169,6 +1169,22 @@ __device__ __forceinline__ int blk_slot_rt(int pair, int S) {
 constexpr int kBlkPairs = 5 * kThreads;        // pairs per buffer: 4 tile chunks + 1 halo chunk
 constexpr int kBlkWOff = kBlkPairs * 16;       // byte offset of the W buffer behind the R buffer
 
+// Thresholding of a detail coefficient as the inverse consumes it (CT = 0: none), for a finite threshold >= 0:
+//   CT 1  apply_thr mode 1 (soft, a NaN coefficient becomes zero): max(|c| - thr, 0) with the sign of c -- a zero may
+//         come out with the other sign, which cannot reach an output (see shrink_finite);
+//   CT 2  apply_thr mode 2 (hard): |c| <= thr ? 0 : c, a NaN coefficient stays;
+//   CT 3  apply_thr mode 3 (soft, a NaN coefficient stays): c - clamp(c, -thr, thr), bit for bit the reference's value
+//         for every finite, infinite or NaN c (|c| <= thr gives c - c = +0.0).
+// Identity settings for a level whose threshold is not such a number (the level is then thresholded in LDS by the
+// general rule first): thr = 0 for CT 1 and CT 3, thr = -1 for CT 2.
+template <int CT>
+__device__ __forceinline__ double consume_thr(double c, double thr) {
+    if (CT == 1) return shrink_finite(c, thr, true);
+    if (CT == 2) return (fabs(c) <= thr) ? 0.0 : c;
+    if (CT == 3) return c - __builtin_fmin(__builtin_fmax(c, -thr), thr);
+    return c;
+}
+
 template <bool FMA>
 __device__ __forceinline__ double inv_pair_mac(double acc, double flo, double r, double fhi, double w) {
     // sum += lo[l]*a[idx] + hi[l]*d[idx]
@@ -1180,9 +1196,9 @@ __device__ __forceinline__ double inv_pair_mac(double acc, double flo, double r,
 // PRELOAD: the whole operand window is requested before the first multiply (a scheduling fence keeps the
 // compiler from sinking the reads next to their uses), so that one wave covers its own LDS latency; costs
 // 8 * (LT + 3) registers and is meant for the two-waves-per-SIMD ring kernel.
-template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false, int CT = 0>
 __device__ __forceinline__ void inv_blk_main(const char* lds, int tid, int SRT, const double (&tl)[LT], const double (&th)[LT],
-                                             double (&acc)[5][2], int& P0out) {
+                                             double (&acc)[5][2], int& P0out, double cthr = 0.0) {
     const int sl = (S >= 4) ? SRT : S;
     const int sp = 1 << sl;
     const int P0 = ((tid >> sl) << (sl + 2)) + (tid & (sp - 1));
@@ -1198,6 +1214,10 @@ __device__ __forceinline__ void inv_blk_main(const char* lds, int tid, int SRT, 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < LT + 3; ++c) {
+            if (CT != 0) {
+                w[c].x = consume_thr<CT>(w[c].x, cthr);
+                w[c].y = consume_thr<CT>(w[c].y, cthr);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int l = c - k;
@@ -1209,6 +1229,7 @@ __device__ __forceinline__ void inv_blk_main(const char* lds, int tid, int SRT, 
         }
         return;
     }
+    static_assert(CT == 0 || PRELOAD, "consume-time thresholding is wired into the preloading forms only");
 #pragma unroll
     for (int c = 0; c < LT + 3; ++c) {
         const int adr = blk_slot<S>(P0 + c * sp) << 4;
@@ -1226,9 +1247,9 @@ __device__ __forceinline__ void inv_blk_main(const char* lds, int tid, int SRT, 
 }
 
 // halo pair of a lane at a blocked level: one pair, tap by tap (wave-uniform switch outside)
-template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+template <int LT, int S, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false, int CT = 0>
 __device__ __forceinline__ void inv_blk_halo(const char* lds, int ph, int SRT, const double (&tl)[LT], const double (&th)[LT],
-                                             double (&acc)[5][2]) {
+                                             double (&acc)[5][2], double cthr = 0.0) {
     const int sl = (S >= 4) ? SRT : S;
     const int sp = 1 << sl;
     if (PRELOAD) {
@@ -1242,11 +1263,12 @@ __device__ __forceinline__ void inv_blk_halo(const char* lds, int ph, int SRT, c
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
-            acc[4][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][0], tl[l], r[l].x, th[l], w[l].x);
-            acc[4][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][1], tl[l], r[l].y, th[l], w[l].y);
+            acc[4][0] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][0], tl[l], r[l].x, th[l], consume_thr<CT>(w[l].x, cthr));
+            acc[4][1] = inv_pair_mac<FMA>(l == 0 ? 0.0 : acc[4][1], tl[l], r[l].y, th[l], consume_thr<CT>(w[l].y, cthr));
         }
         return;
     }
+    static_assert(CT == 0 || PRELOAD, "consume-time thresholding is wired into the preloading forms only");
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
         const int adr = blk_slot<S>(ph + l * sp) << 4;
@@ -1258,9 +1280,9 @@ __device__ __forceinline__ void inv_blk_halo(const char* lds, int ph, int SRT, c
 }
 
 // level 1: chunk ownership, window of LT/2 + 1 aligned pairs per operand
-template <int LT, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false>
+template <int LT, bool FMA, int WOFF = kBlkWOff, bool PRELOAD = false, int CT = 0>
 __device__ __forceinline__ void inv_blk_level1(const char* lds, int tid, const double (&tl)[LT], const double (&th)[LT],
-                                               double (&acc)[5][2]) {
+                                               double (&acc)[5][2], double cthr = 0.0) {
     constexpr int NW = LT / 2 + 1;
     if (PRELOAD) {
         // two chunks' windows at a time
@@ -1276,6 +1298,15 @@ __device__ __forceinline__ void inv_blk_level1(const char* lds, int tid, const d
                     ww[kk][q] = *reinterpret_cast<const double2*>(lds + WOFF + adr);
                 }
             __builtin_amdgcn_sched_barrier(0);
+            if (CT != 0) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        ww[kk][q].x = consume_thr<CT>(ww[kk][q].x, cthr);
+                        ww[kk][q].y = consume_thr<CT>(ww[kk][q].y, cthr);
+                    }
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1291,6 +1322,7 @@ __device__ __forceinline__ void inv_blk_level1(const char* lds, int tid, const d
         }
         return;
     }
+    static_assert(CT == 0 || PRELOAD, "consume-time thresholding is wired into the preloading forms only");
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double r[2 * NW], w[2 * NW];
@@ -1546,8 +1578,9 @@ __device__ __forceinline__ void ring_writeback(char* lds, const double (&acc)[5]
     }
 }
 
-template <int LT, int MODE, bool FMA, bool PLAIN>
+template <int LT, int MODE, bool FMA, bool PLAIN, int TH = 0>
 __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
+    static_assert(TH == 0 || PLAIN, "consume-time thresholding goes with the plain staging");
     extern __shared__ double2 vw_smem[];
     constexpr int PPT = 4, NP = 5;
     constexpr int T = PPT * kChunk;
@@ -1598,14 +1631,21 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (!PLAIN || edge) {
+        // TH != 0 (a denoise with nothing else to do to the bands): the level's threshold is applied to the W operands
+        // as the arithmetic consumes them, and the pass below only runs where it is needed anyway (zeros right of a
+        // ZERO_PADDING row) or where the threshold is no finite non-negative number -- then it applies the general
+        // rule in LDS and the consumers get the identity setting
+        const double thr_j = (TH != 0 || (!PLAIN && a.thr_mode != 0))
+                                 ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
+        const bool thr_plain = finite_f64(thr_j) && thr_j >= 0.0;
+        const double cthr = (TH == 0) ? 0.0 : (thr_plain ? thr_j : (TH == 2 ? -1.0 : 0.0));
+        if (!PLAIN || edge || (TH != 0 && !thr_plain)) {
             // pass over the slots this wave has filled: W_j (and R on the first level).  Kept lean -- it runs once per
             // level on 5 slots per lane: finite values under a finite non-negative threshold take the three-instruction
             // form of the thresholding rule (a wave-uniform choice), and the non-finite report, which needs 64-bit
             // index arithmetic and atomics, is a second loop that only a wave holding such a value enters.
-            const int mode = a.thr_mode;
-            const double thr = (mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
-            const bool thr_plain = finite_f64(thr) && thr >= 0.0;
+            const int mode = (TH != 0) ? (thr_plain ? 0 : a.thr_mode) : (PLAIN ? 0 : a.thr_mode);
+            const double thr = thr_j;
             const bool use_w = (a.band_mask >> (j - 1)) & 1u;
             const bool use_r = (a.band_mask >> 31) & 1u;
             const int wofs = (1 + j % 3) * kRingBand;
@@ -1705,10 +1745,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_inv_ring(const InvArgs a) {
             P0 = ((tid >> (S < 0 ? 0 : S)) << ((S < 0 ? 0 : S) + 2)) + (tid & ((1 << (S < 0 ? 0 : S)) - 1));
         } else
 #define VW_RING_LEVEL(SS, SLOT)                                                                         \
-    inv_blk_main<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, tid, S, tl, th, acc, P0);              \
-    if (hact) inv_blk_halo<LT, SS, FMA, (1 + SLOT) * kRingBand, true>(lds, ph, S, tl, th, acc);
+    inv_blk_main<LT, SS, FMA, (1 + SLOT) * kRingBand, true, TH>(lds, tid, S, tl, th, acc, P0, cthr);    \
+    if (hact) inv_blk_halo<LT, SS, FMA, (1 + SLOT) * kRingBand, true, TH>(lds, ph, S, tl, th, acc, cthr);
         switch (j) {
-            case 1: inv_blk_level1<LT, FMA, (1 + 1) * kRingBand, true>(lds, tid, tl, th, acc); break;
+            case 1: inv_blk_level1<LT, FMA, (1 + 1) * kRingBand, true, TH>(lds, tid, tl, th, acc, cthr); break;
             case 2: VW_RING_LEVEL(0, 2) break;
             case 3: VW_RING_LEVEL(1, 0) break;
             case 4: VW_RING_LEVEL(2, 1) break;

@@ -55,6 +55,13 @@ hipError_t launch_inv_blk(const InvArgs& a, int mode, bool vec2, bool fma, int64
 // LDS-DMA ring form of the register-blocked kernel (16-byte-aligned rows only)
 template <int LT, int MODE>
 static hipError_t launch_inv_ring_pm(const InvArgs& a, bool fma, bool plain, int64_t nblocks, size_t lds, hipStream_t stream) {
+    // a denoise that only thresholds (every band used, no finite check), reference arithmetic: the threshold is
+    // applied as the operands are consumed (thr_mode 1, 2, 3 -> the kernel's TH)
+    if (!fma && a.thr_mode != 0 && a.first_bad == nullptr && a.band_mask == 0xffffffffu) {
+        if (a.thr_mode == 1) return launch_tile(k_inv_ring<LT, MODE, false, true, 1>, a, nblocks, lds, stream);
+        if (a.thr_mode == 2) return launch_tile(k_inv_ring<LT, MODE, false, true, 2>, a, nblocks, lds, stream);
+        return launch_tile(k_inv_ring<LT, MODE, false, true, 3>, a, nblocks, lds, stream);
+    }
     if (plain) return fma ? launch_tile(k_inv_ring<LT, MODE, true, true>, a, nblocks, lds, stream)
                           : launch_tile(k_inv_ring<LT, MODE, false, true>, a, nblocks, lds, stream);
     return fma ? launch_tile(k_inv_ring<LT, MODE, true, false>, a, nblocks, lds, stream)
