@@ -48,6 +48,7 @@ struct PlanOptions {
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
     int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
     int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
+    int inv_wave = 0;                    // >= 1: one wavefront per run of that many 512-sample chunks (k_inv_wave6) where it applies
     int carry_chunks = 0;                // >= 2: the ring kernel over runs of that many tiles with carried right contexts
                                          // (k_inv_carry); measured 5-7 % slower than one tile per workgroup, so off by default
     int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
@@ -171,6 +172,9 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
     PlanOptions& o = ctx->opt;
     if (strcmp(name, "reset") == 0) {
         o = PlanOptions();
+#ifdef VW_TUNING
+        if (const char* e = getenv("VW_ABLATE")) snprintf(o.ablate, sizeof(o.ablate), "%s", e);  // ablations survive a reset
+#endif
     } else if (strcmp(name, "fwd_tile") == 0) {
         if (!parse_pair(value, &o.fwd_tile_p, &o.fwd_tile_h)) return set_err(ctx, VW_E_UNSUPPORTED, "bad tile shape %lld", static_cast<long long>(value));
     } else if (strcmp(name, "inv_tile") == 0) {
@@ -201,6 +205,8 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_blk = value != 0;
     } else if (strcmp(name, "no_ring") == 0) {
         o.no_ring = value != 0;
+    } else if (strcmp(name, "inv_wave") == 0) {
+        o.inv_wave = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "carry_chunks") == 0) {
         o.carry_chunks = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_wide_inv") == 0) {
@@ -222,7 +228,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
+                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -1083,6 +1089,19 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             // opt-in: runs of tiles with carried right contexts
             bool carry = ring && ctx->opt.carry_chunks >= 2 && a.ntiles > 1 && inv_carry_supported(a.lh, st.lev0, st.lev1);
             int64_t nlaunch = nblocks;
+            const bool plain_inv = thr_mode == 0 && first_bad_cell == nullptr && a.band_mask == 0xffffffffu;
+            const bool wave = ctx->opt.inv_wave >= 1 && vec2 && plain_inv && lgr == lhr &&
+                              inv_wave_supported(a.lh, st.lev0, st.lev1, boundary, n) && ctx->lds_limit >= 32768;
+            if (wave) {
+                const int64_t chunks = n / 512;
+                const int64_t nch = ctx->opt.inv_wave < chunks ? ctx->opt.inv_wave : chunks;
+                a.tiles_per_row = static_cast<int32_t>(chunks);
+                a.nchunks = static_cast<int32_t>(nch);
+                a.ntiles = static_cast<int32_t>((chunks + nch - 1) / nch);
+                a.ndry = inv_wave_ndry(a.lh, st.lev1);
+                nlaunch = b * a.ntiles;
+                carry = false;
+            }
             if (carry) {
                 const int64_t tiles = a.ntiles;
                 const int64_t nch = ctx->opt.carry_chunks < tiles ? ctx->opt.carry_chunks : tiles;
@@ -1091,8 +1110,9 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                 a.ntiles = static_cast<int32_t>((tiles + nch - 1) / nch);
                 nlaunch = b * a.ntiles;
             }
-            plan_note(ctx->plan_inv, carry ? "k_inv_carry" : ring ? "k_inv_ring" : blk ? "k_inv_blk" : "k_inv_fused", st.lev0, st.lev1);
-            hipError_t er = carry ? launch_inv_carry(a, boundary, (flags & VW_FLAG_FMA) != 0, nlaunch, stream)
+            plan_note(ctx->plan_inv, wave ? "k_inv_wave" : carry ? "k_inv_carry" : ring ? "k_inv_ring" : blk ? "k_inv_blk" : "k_inv_fused", st.lev0, st.lev1);
+            hipError_t er = wave ? launch_inv_wave(a, boundary, (flags & VW_FLAG_FMA) != 0, nlaunch, stream)
+                            : carry ? launch_inv_carry(a, boundary, (flags & VW_FLAG_FMA) != 0, nlaunch, stream)
                             : ring ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                             : blk ? launch_inv_blk(a, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                                   : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);

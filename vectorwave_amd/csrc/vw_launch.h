@@ -39,6 +39,11 @@ hipError_t launch_inv_ring(const InvArgs& a, int mode, bool fma, int64_t nblocks
 // a.tiles_per_row tiles in all; inv_carry_supported tells whether the heads of this filter / level group fit the storage
 bool inv_carry_supported(int taps, int lev0, int lev1);
 hipError_t launch_inv_carry(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
+// one wavefront per run of chunks, no workgroup barriers (k_inv_wave6): a.ntiles runs per row of a.nchunks chunks of 512
+// samples, a.tiles_per_row chunks in all, a.ndry warm-up chunks
+bool inv_wave_supported(int taps, int lev0, int lev1, int mode, int64_t n);
+int inv_wave_ndry(int taps, int lev1);
+hipError_t launch_inv_wave(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
 hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 // vec2: global access mode (0 one sample per access, 1 aligned pairs, 2 pairs at 8-byte alignment)
 hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, int vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
