@@ -48,7 +48,8 @@ struct PlanOptions {
     int no_row_denoise = 0;              // 1: the SWT denoise always materialises the coefficient block
     int no_blk = 0;                      // 1: the inverse tile kernel without register blocking (k_inv_fused)
     int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
-    int inv_wave = 0;                    // >= 1: one wavefront per run of that many 512-sample chunks (k_inv_wave6) where it applies
+    int inv_wave = 0;                    // one wavefront per run of 512-sample chunks (k_inv_wave6): 0 = where it pays (large
+                                         // batches), -1 = never, N >= 1 = wherever it applies, runs of N chunks
     int carry_chunks = 0;                // >= 2: the ring kernel over runs of that many tiles with carried right contexts
                                          // (k_inv_carry); measured 5-7 % slower than one tile per workgroup, so off by default
     int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
@@ -78,6 +79,7 @@ struct vw_ctx {
     DevBuf ws_borrow;   // set (under mu) by an entry point that may not allocate: stands in for `ws`, never freed
     void* scratch = nullptr;  // this device's copy of the static scratch array (looked up in vw_init)
     int lds_limit = 65536;
+    int num_cus = 256;
     PlanOptions opt;
 };
 
@@ -206,7 +208,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
     } else if (strcmp(name, "no_ring") == 0) {
         o.no_ring = value != 0;
     } else if (strcmp(name, "inv_wave") == 0) {
-        o.inv_wave = value > 0 ? static_cast<int>(value) : 0;
+        o.inv_wave = value > 0 ? static_cast<int>(value < 1000000 ? value : 1000000) : (value < 0 ? -1 : 0);
     } else if (strcmp(name, "carry_chunks") == 0) {
         o.carry_chunks = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_wide_inv") == 0) {
@@ -267,6 +269,7 @@ extern "C" int32_t vw_init(int32_t device, vw_ctx** out_ctx) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->lds_limit = static_cast<int>(prop.sharedMemPerBlock);
+        if (prop.multiProcessorCount > 0) ctx->num_cus = prop.multiProcessorCount;
         if (strncmp(prop.gcnArchName, "gfx950", 6) == 0 && ctx->lds_limit < 160 * 1024) ctx->lds_limit = 160 * 1024;
         snprintf(ctx->info, sizeof(ctx->info),
                  "HIP device %d: %s (%s), %d CUs, %.0f GiB HBM, %d KiB LDS/workgroup; fp64 MODWT kernels: "
@@ -1090,17 +1093,34 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             bool carry = ring && ctx->opt.carry_chunks >= 2 && a.ntiles > 1 && inv_carry_supported(a.lh, st.lev0, st.lev1);
             int64_t nlaunch = nblocks;
             const bool plain_inv = thr_mode == 0 && first_bad_cell == nullptr && a.band_mask == 0xffffffffu;
-            const bool wave = ctx->opt.inv_wave >= 1 && vec2 && plain_inv && lgr == lhr &&
-                              inv_wave_supported(a.lh, st.lev0, st.lev1, boundary, n) && ctx->lds_limit >= 32768;
+            // one wavefront per run of chunks: wins once every CU holds its five waves several times over and the runs are
+            // long enough for the warm-up chunk not to matter; below that the tile kernels stay
+            bool wave = ctx->opt.inv_wave >= 0 && vec2 && plain_inv && inv_wave_supported(a.lh, st.lev0, st.lev1, boundary, n) &&
+                        ctx->lds_limit >= 32768;
             if (wave) {
-                const int64_t chunks = n / 512;
-                const int64_t nch = ctx->opt.inv_wave < chunks ? ctx->opt.inv_wave : chunks;
-                a.tiles_per_row = static_cast<int32_t>(chunks);
-                a.nchunks = static_cast<int32_t>(nch);
-                a.ntiles = static_cast<int32_t>((chunks + nch - 1) / nch);
-                a.ndry = inv_wave_ndry(a.lh, st.lev1);
-                nlaunch = b * a.ntiles;
-                carry = false;
+                const int64_t chunks = (n + 511) / 512;
+                const int ndry = inv_wave_ndry(a.lh, st.lev1);
+                int64_t nch;
+                if (ctx->opt.inv_wave >= 1) {
+                    nch = ctx->opt.inv_wave < chunks ? ctx->opt.inv_wave : chunks;
+                    if (nch < ndry) nch = ndry;
+                } else {
+                    const int64_t want_waves = 16 * 5 * static_cast<int64_t>(ctx->num_cus);
+                    int64_t runs = (want_waves + b - 1) / b;
+                    if (runs > chunks / 16) runs = chunks / 16;
+                    if (runs < 1) runs = 1;
+                    nch = (chunks + runs - 1) / runs;
+                    if (b * chunks < 4 * want_waves || chunks < 8) wave = false;
+                }
+                if (wave) {
+                    a.tiles_per_row = static_cast<int32_t>(chunks);
+                    a.nchunks = static_cast<int32_t>(nch);
+                    a.ntiles = static_cast<int32_t>((chunks + nch - 1) / nch);
+                    a.ndry = ndry;
+                    nlaunch = b * a.ntiles;
+                    if (nlaunch > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+                    carry = false;
+                }
             }
             if (carry) {
                 const int64_t tiles = a.ntiles;

@@ -4,19 +4,30 @@
 
 namespace vw {
 
-// one wavefront per run of 512-sample chunks (k_inv_wave6): levels 6..1, 8-tap filters, PERIODIC rows of a multiple of 512 samples
+// one wavefront per run of 512-sample chunks (k_inv_wave6): levels 6..1, filters of 2, 4 or 8 taps, PERIODIC or
+// ZERO_PADDING rows of even length
 bool inv_wave_supported(int taps, int lev0, int lev1, int mode, int64_t n) {
-    return taps == 8 && lev0 == 1 && lev1 == 6 && mode == kPeriodic && n % kWvSamples == 0 && n >= 2 * kWvSamples;
+    return (taps == 2 || taps == 4 || taps == 8) && lev0 == 1 && lev1 == 6 && (mode == kPeriodic || mode == kZeroPad) && n % 2 == 0 &&
+           n >= 2 * kWvSamples;
 }
 int inv_wave_ndry(int taps, int lev1) {
     const int ctx = (taps - 1) * ((1 << lev1) - 1);
     return (ctx + kWvSamples - 1) / kWvSamples;
 }
+template <int LT>
+static hipError_t launch_inv_wave_lt(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
+    const size_t lds = wv_lds_bytes(LT, 6);
+    if (mode == kPeriodic)
+        return fma ? launch_tile_nt(k_inv_wave6<LT, kPeriodic, true>, a, 64, nblocks, lds, stream)
+                   : launch_tile_nt(k_inv_wave6<LT, kPeriodic, false>, a, 64, nblocks, lds, stream);
+    return fma ? launch_tile_nt(k_inv_wave6<LT, kZeroPad, true>, a, 64, nblocks, lds, stream)
+               : launch_tile_nt(k_inv_wave6<LT, kZeroPad, false>, a, 64, nblocks, lds, stream);
+}
 hipError_t launch_inv_wave(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
-    (void)mode;
-    const size_t lds = wv_lds_bytes(8, 6);
-    return fma ? launch_tile_nt(k_inv_wave6<8, true>, a, 64, nblocks, lds, stream)
-               : launch_tile_nt(k_inv_wave6<8, false>, a, 64, nblocks, lds, stream);
+    if (a.lh == 2) return launch_inv_wave_lt<2>(a, mode, fma, nblocks, stream);
+    if (a.lh == 4) return launch_inv_wave_lt<4>(a, mode, fma, nblocks, stream);
+    if (a.lh == 8) return launch_inv_wave_lt<8>(a, mode, fma, nblocks, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace vw

@@ -48,8 +48,19 @@ constexpr int wv_slot_w(int J, int j) { return kWvBuf * (1 + ((J - j + 1) & 3));
 // address `ldst`, in the layout of the level that reads it (`voff`: the lane's swizzled byte offset inside a 1 KiB block).
 __device__ __forceinline__ void wv_issue(const double* __restrict__ band_row, int64_t t0, unsigned voff, unsigned ldst) {
     const double* tsrc = band_row + t0;  // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16_so(tsrc, voff + 1024u * i, ldst + 1024u * i);
+    // the instruction's immediate offset is added to the global address AND to the LDS address: one M0, one address
+    // register and one offset register serve the four 1 KiB blocks
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(tsrc), "s"(ldst)
+        : "memory");
 }
 
 // 16-byte store to a wave-uniform base plus a 32-bit byte offset per lane.  Written out so that the address stays an SGPR
@@ -257,9 +268,41 @@ __device__ __forceinline__ void wv_level1(char* lds, int lane, const WvLevel1Add
     }
 }
 
-// Levels 6 .. 1 of a PERIODIC row whose length is a multiple of 512 samples.  a.ntiles = runs per row (counted from
-// the right end of the row), a.nchunks = chunks per run, a.tiles_per_row = chunks per row, a.ndry = warm-up chunks.
-template <int LT, bool FMA>
+// The same four LDS-DMA instructions for a chunk that reaches beyond its row (the last, partial chunk of a row and the
+// warm-up chunks behind it): the source wraps (PERIODIC) or is clamped to valid memory (ZERO_PADDING: the values are
+// replaced by zeros once they have landed) lane by lane.  S: log2 stride of the reading level (-1: level 1).
+template <int MODE>
+__device__ __forceinline__ void wv_issue_edge(const double* __restrict__ band_row, int64_t t0, int64_t n, int S, int lane, unsigned ldst) {
+    // (an opaque copy of the lane index: without it the compiler computes the pair indices of every level once per run and
+    // keeps them in registers across the chunk loop, for a path that one chunk per row takes)
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pair = blk_slot_rt(64 * i + lane, S);
+        int64_t t = t0 + 2 * pair;
+        if (t >= n) t = (MODE == kPeriodic) ? t - n : n - 2;
+        glds16(band_row + t, ldst + 1024u * i);
+    }
+}
+
+// ZERO_PADDING: zeros right of the signal in a freshly landed band chunk (slot at byte offset `slot`, layout of the level
+// with log2 stride S)
+__device__ __forceinline__ void wv_zero_tail(char* lds, int slot, int64_t t0, int64_t n, int S, int lane) {
+    asm volatile("" : "+v"(lane));  // (as in wv_issue_edge)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pair = blk_slot_rt(64 * i + lane, S);
+        if (t0 + 2 * pair >= n) *reinterpret_cast<double2*>(lds + slot + ((64 * i + lane) << 4)) = make_double2(0.0, 0.0);
+    }
+}
+
+// Levels 6 .. 1 of rows of even length n >= 1024, PERIODIC or ZERO_PADDING, both filters of LT taps.
+// a.ntiles = runs per row (counted from the right end of the row), a.nchunks = chunks per run (>= a.ndry),
+// a.tiles_per_row = chunks per row (the last one may be partial), a.ndry = warm-up chunks.
+// Chunk c covers the samples [512 c, 512 c + 512) of the row extended by its boundary rule; a PERIODIC run at the right
+// end of the row warms up on the chunks behind the row end, i.e. on the wrapped start of the row; a ZERO_PADDING run
+// there needs no warm-up: right of the row everything is zero at every level, and the heads start as zeros.
+template <int LT, int MODE, bool FMA>
 __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     constexpr int J = 6;
     extern __shared__ double2 vw_smem[];
@@ -270,10 +313,11 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     const int64_t id = blockIdx.x;
     const int64_t row = id / a.ntiles;
     const int run = static_cast<int>(id - row * a.ntiles);
+    const int64_t n = a.n;
     const int nch_row = a.tiles_per_row;
     const int c_hi = nch_row - 1 - run * a.nchunks;
     const int nreal = (c_hi + 1 < a.nchunks) ? c_hi + 1 : a.nchunks;
-    const int ndry = a.ndry;
+    const int ndry = (MODE == kZeroPad && run == 0) ? 0 : a.ndry;
     const int nsteps = ndry + nreal;
     const bool nomath = VW_ABLATED(a, 0);
     const bool noload = VW_ABLATED(a, 1);
@@ -288,10 +332,13 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     const double* __restrict__ wrow = a.win + row * a.w_row_stride;
     double* __restrict__ orow = a.rout + row * a.rout_stride;
     auto wband = [&](int j) { return wrow + static_cast<int64_t>(j - 1) * a.w_band_stride; };
+    // first sample of the chunk of step st (wrapped into the row when it lies behind the row end), and whether the chunk
+    // reaches beyond the row end from there
     auto chunk_t0 = [&](int st) -> int64_t {
-        int c = (st < ndry) ? c_hi + ndry - st : c_hi - (st - ndry);
-        if (c >= nch_row) c -= nch_row;
-        return static_cast<int64_t>(c) * kWvSamples;
+        const int c = (st < ndry) ? c_hi + ndry - st : c_hi - (st - ndry);
+        int64_t t0 = static_cast<int64_t>(c) * kWvSamples;
+        if (t0 >= n) t0 -= n;  // PERIODIC warm-up behind the row end (n >= 2 chunks: one wrap)
+        return t0;
     };
 
     // the lane's swizzled byte offset inside a 1 KiB block, per reading level (level 1 and level 6 read unswizzled)
@@ -306,21 +353,29 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     wv_addr_init<LT, J, 2>(lane, A2);
     wv_addr1_init<LT, J>(lane, A1);
 
-    // heads start as zeros (any finite value would do: the warm-up chunks replace them before they matter)
+    // heads start as zeros (ZERO_PADDING at the row end needs exactly that; elsewhere any finite value would do: the
+    // warm-up chunks replace them before they matter)
     {
         constexpr int NHP = 2 * wv_hoff(LT, J + 1);
         for (int i = lane; i < NHP; i += 64) *reinterpret_cast<double2*>(lds + kWvHeads + (i << 4)) = make_double2(0.0, 0.0);
     }
 
+    // one band chunk on its way: S = log2 stride of the level that reads it, voff = the lane's offset in that layout
+    auto issue = [&](const double* band_row, int64_t t0, int S, int voff, int slot) {
+        if (noload) return;
+        if (t0 + kWvSamples > n)
+            wv_issue_edge<MODE>(band_row, t0, n, S, lane, lds_base + slot);
+        else
+            wv_issue(band_row, t0, voff, lds_base + slot);
+    };
+
     // prologue: the first four bands of the first chunk
     {
         const int64_t t0 = chunk_t0(0);
-        if (!noload) {
-            wv_issue(arow, t0, vsid, lds_base + wv_slot_a());
-            wv_issue(wband(6), t0, vsid, lds_base + wv_slot_w(J, 6));
-            wv_issue(wband(5), t0, vs3, lds_base + wv_slot_w(J, 5));
-            wv_issue(wband(4), t0, vs2, lds_base + wv_slot_w(J, 4));
-        }
+        issue(arow, t0, 4, vsid, wv_slot_a());
+        issue(wband(6), t0, 4, vsid, wv_slot_w(J, 6));
+        issue(wband(5), t0, 3, vs3, wv_slot_w(J, 5));
+        issue(wband(4), t0, 2, vs2, wv_slot_w(J, 4));
     }
 
     for (int st = 0; st < nsteps; ++st) {
@@ -328,30 +383,47 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
         const int pst = (st > ndry) ? 4 : 0;  // the previous chunk's four stores are still counted
         const int64_t t0 = chunk_t0(st);
         const int64_t tn = last ? 0 : chunk_t0(st + 1);
-        const bool pf = !last && !noload;
+        const bool pf = !last;
+        const bool ztail = (MODE == kZeroPad) && (t0 + kWvSamples > n);  // zeros right of the signal
 
         wv_wait_vm(noload ? 0 : 8 + pst);  // a_6 and W_6 have landed (W_5, W_4 and the stores may be in flight)
-        wv_level<LT, J, 6, FMA>(lds, lane, A6, vsid, tl, th, nomath, [&] { if (!noload) wv_issue(wband(3), t0, vs1, lds_base + wv_slot_w(J, 3)); });
+        if (ztail) {
+            wv_zero_tail(lds, wv_slot_a(), t0, n, 4, lane);
+            wv_zero_tail(lds, wv_slot_w(J, 6), t0, n, 4, lane);
+        }
+        wv_level<LT, J, 6, FMA>(lds, lane, A6, vsid, tl, th, nomath, [&] { issue(wband(3), t0, 1, vs1, wv_slot_w(J, 3)); });
         wv_wait_vm(noload ? 0 : 8 + pst);  // W_5
-        wv_level<LT, J, 5, FMA>(lds, lane, A5, vs3, tl, th, nomath, [&] { if (!noload) wv_issue(wband(2), t0, vs0, lds_base + wv_slot_w(J, 2)); });
+        if (ztail) wv_zero_tail(lds, wv_slot_w(J, 5), t0, n, 3, lane);
+        wv_level<LT, J, 5, FMA>(lds, lane, A5, vs3, tl, th, nomath, [&] { issue(wband(2), t0, 0, vs0, wv_slot_w(J, 2)); });
         wv_wait_vm(noload ? 0 : 8 + pst);  // W_4
-        wv_level<LT, J, 4, FMA>(lds, lane, A4, vs2, tl, th, nomath, [&] { if (!noload) wv_issue(wband(1), t0, vsid, lds_base + wv_slot_w(J, 1)); });
+        if (ztail) wv_zero_tail(lds, wv_slot_w(J, 4), t0, n, 2, lane);
+        wv_level<LT, J, 4, FMA>(lds, lane, A4, vs2, tl, th, nomath, [&] { issue(wband(1), t0, -1, vsid, wv_slot_w(J, 1)); });
         wv_wait_vm(noload ? 0 : 8);  // W_3
-        wv_level<LT, J, 3, FMA>(lds, lane, A3, vs1, tl, th, nomath, [&] { if (pf) wv_issue(arow, tn, vsid, lds_base + wv_slot_a()); });
+        if (ztail) wv_zero_tail(lds, wv_slot_w(J, 3), t0, n, 1, lane);
+        wv_level<LT, J, 3, FMA>(lds, lane, A3, vs1, tl, th, nomath, [&] { if (pf) issue(arow, tn, 4, vsid, wv_slot_a()); });
         wv_wait_vm(noload ? 0 : (last ? 4 : 8));  // W_2
-        wv_level<LT, J, 2, FMA>(lds, lane, A2, vs0, tl, th, nomath, [&] { if (pf) wv_issue(wband(6), tn, vsid, lds_base + wv_slot_w(J, 6)); });
+        if (ztail) wv_zero_tail(lds, wv_slot_w(J, 2), t0, n, 0, lane);
+        wv_level<LT, J, 2, FMA>(lds, lane, A2, vs0, tl, th, nomath, [&] { if (pf) issue(wband(6), tn, 4, vsid, wv_slot_w(J, 6)); });
         wv_wait_vm(noload ? 0 : (last ? 0 : 8));  // W_1
+        if (ztail) wv_zero_tail(lds, wv_slot_w(J, 1), t0, n, -1, lane);
         double out[4][2];
         wv_level1<LT, J, FMA>(lds, lane, A1, tl, th, nomath, out, [&] {
             if (pf) {
-                wv_issue(wband(5), tn, vs3, lds_base + wv_slot_w(J, 5));
-                wv_issue(wband(4), tn, vs2, lds_base + wv_slot_w(J, 4));
+                issue(wband(5), tn, 3, vs3, wv_slot_w(J, 5));
+                issue(wband(4), tn, 2, vs2, wv_slot_w(J, 4));
             }
         });
-        if (!dry && t0 < a.n_store) {  // (rows are a multiple of the chunk: a chunk lies inside the row or outside)
+        if (!dry && t0 < a.n_store) {
             double* __restrict__ cb = orow + t0;  // wave-uniform
+            if (t0 + kWvSamples <= n) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wv_store16(cb, static_cast<unsigned>(vsid + 1024 * kk), make_double2(out[kk][0], out[kk][1]), a.nt_store);
+                for (int kk = 0; kk < 4; ++kk) wv_store16(cb, static_cast<unsigned>(vsid + 1024 * kk), make_double2(out[kk][0], out[kk][1]), a.nt_store);
+            } else {  // the last, partial chunk of the row
+                const int rem = static_cast<int>(n - t0);  // samples of the chunk inside the row (< 512)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    if (2 * (kk * 64 + lane) < rem) wv_store16(cb, static_cast<unsigned>(vsid + 1024 * kk), make_double2(out[kk][0], out[kk][1]), a.nt_store);
+            }
         }
     }
 }
