@@ -392,13 +392,22 @@ def main():
     inv_name = kern.get("inverse", "?").split("[")[0]
     dom_name, dom_ms = (inv_name, inv_ms) if inv_ms >= fwd_ms else (fwd_name, fwd_ms)
     achieved = bytes_per_dir / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/prof_round.sh).  The figure is
+    # a measurement of ONE build: it is reported only while the library loaded here is that build (SHA-256 digest),
+    # otherwise the line says traffic null / traffic_stale true.
+    traffic, traffic_stale = None, False
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
+            import hashlib
             tj = json.load(open(tpath))
             key = "%s:%dx%d:J%d:%s" % (dom_name, rows, n, J, args.wavelet)
-            traffic = tj.get(key)
+            det = tj.get(key + ":detail") or {}
+            have = hashlib.sha256(open(N.LIB_PATH, "rb").read()).hexdigest()[:16]
+            if key in tj and det.get("lib_digest") == have:
+                traffic = tj[key]
+            elif key in tj:
+                traffic_stale = True
         except Exception:
             traffic = None
     out = {
@@ -432,7 +441,7 @@ def main():
         "other_scaling": other_scaling,
         "roofline": {
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
             "algorithmic_bytes_per_launch": bytes_per_dir,
             "plan": plan_txt,
             "other_kernel": {"kernel": fwd_name if inv_ms >= fwd_ms else inv_name,

@@ -102,6 +102,7 @@ def main():
     print("wrote %d cases, %.1f KiB" % (len(names), sz / 1024))
     make_extra()
     make_streaming()
+    make_seeded()
 
 
 # second fixture: the WaveletDenoiser path and level groups with a long context (more than one
@@ -183,5 +184,73 @@ def make_streaming():
     print("wrote %d streaming cases, %.1f KiB" % (len(names), os.path.getsize(path) / 1024))
 
 
+# fourth fixture: the reference tests' own seeded inputs.  Those tests draw from java.util.Random(42).nextGaussian();
+# tools/java_random.py restates that generator (48-bit LCG, polar method, fdlibm log) so the inputs are the reference's
+# bit for bit.  What the reference asserts on them are properties (batch == per-signal at 1e-10, parallel ==
+# sequential, "zeroes some, keeps some", shapes); the fixture keeps the inputs and the oracle's outputs on them.
+def make_seeded():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from java_random import JavaRandom
+    arrays = {}
+    db4, haar = get_wavelet("db4"), get_wavelet("haar")
+    # modwt/BatchSIMDMODWTTest.java:104-151: 16 signals x 64 samples, Random(42), row by row
+    r = JavaRandom(42)
+    xb = np.array([[r.next_gaussian() for _ in range(64)] for _ in range(16)])
+    arrays["batch_db4_x"] = xb
+    arrays["batch_db4_coeffs"] = o.modwt_forward_batch(xb, db4, 0)
+    a, d = o.batch_modwt_soa(o.convert_to_soa(xb), db4, 16, 64)
+    arrays["batch_db4_soa_approx"], arrays["batch_db4_soa_detail"] = a, d
+    # modwt/BatchSIMDMODWTTest.java:153-183: 7 signals x 32 samples, b + t * 0.1 (exact arithmetic)
+    x7 = np.array([[b + t * 0.1 for t in range(32)] for b in range(7)])
+    arrays["batch_haar7_x"] = x7
+    a, d = o.batch_modwt_soa(o.convert_to_soa(x7), haar, 7, 32)
+    arrays["batch_haar7_soa_approx"], arrays["batch_haar7_soa_detail"] = a, d
+    # modwt/ParallelMultiLevelMODWTTest.java:64-100: 128 samples, Random(42), DB4, 4 levels, PERIODIC
+    r = JavaRandom(42)
+    xp = np.array([r.next_gaussian() for _ in range(128)])
+    arrays["parallel_db4_x"] = xp
+    st, c = o.decompose_batch(xp[None], db4, 4, 0)
+    assert st == 0
+    arrays["parallel_db4_coeffs"] = c[0]
+    st, cp = o.parallel_decompose(xp, db4, 4, 0)
+    assert st == 0
+    arrays["parallel_db4_parallel_coeffs"] = cp
+    # swt/VectorWaveSwtAdapterTest.java:243-268 with :423-439: sin(2 pi i / 16) + 0.5 cos(4 pi i / 16) + 0.1 * gaussian,
+    # Random(42), DB4, 4 levels, universal soft threshold.  (Math.sin / Math.cos of the JVM and of the C library may
+    # differ in the last bit, so this input is the reference's only up to that.)
+    r = JavaRandom(42)
+    i = np.arange(256)
+    clean = np.sin(2 * np.pi * i / 16.0) + 0.5 * np.cos(4 * np.pi * i / 16.0)
+    xs = np.array([clean[k] + 0.1 * r.next_gaussian() for k in range(256)])
+    arrays["swt_universal_x"] = xs
+    st, cs = o.decompose_batch(xs[None], db4, 4, 0)
+    assert st == 0
+    thr = o.universal_threshold(cs[0, 0])
+    arrays["swt_universal_thr"] = np.array([thr])
+    ct = cs.copy()
+    for lev in range(4):
+        ct[0, lev] = o.apply_threshold(cs[0, lev], thr, True)
+    arrays["swt_universal_thresholded"] = ct[0]
+    st, y = o.swt_denoise_batch(xs[None], db4, 4, -1.0, True, 0)
+    assert st == 0
+    arrays["swt_universal_denoised"] = y[0]
+    # integration/SimplifiedAPIWorkflowTest.java:103-144 with :231-237: 32 sine waves of 777 samples, DB4 PERIODIC
+    # forwardBatch, softThreshold(detail, 0.1), inverseBatch (same remark on Math.sin)
+    xw = np.array([[1.0 * np.sin(2 * np.pi * (0.01 * (k + 1)) * t) for t in range(777)] for k in range(32)])
+    arrays["workflow_x"] = xw
+    cw = o.modwt_forward_batch(xw, db4, 0)
+    arrays["workflow_coeffs"] = cw
+    cm = cw.copy()
+    for k in range(32):
+        cm[k, 0] = o.soft_threshold(cw[k, 0], 0.1)
+    arrays["workflow_reconstructed"] = o.modwt_inverse_batch(cm, db4, 0)
+    path = os.path.join(OUT, "reference_seeded.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote the reference tests' seeded inputs, %.1f KiB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "seeded":
+        make_seeded()
+    else:
+        main()

@@ -16,7 +16,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <int N> __device__ __forceinline__ void wait_vm();
 #define WV(N) template <> __device__ __forceinline__ void wait_vm<N>() { asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); }
-WV(0) WV(3) WV(4) WV(5) WV(10) WV(6) WV(8) WV(12) WV(15) WV(16) WV(24) WV(30) WV(32) WV(48) WV(60)
+WV(0) WV(2) WV(3) WV(4) WV(5) WV(10) WV(6) WV(8) WV(12) WV(15) WV(16) WV(24) WV(30) WV(32) WV(48) WV(60)
 
 // ORDER 0: right to left, 1: left to right.  BAR: barrier per band (multi-wave workgroups)
 template <int WAVES, int KB, int ORDER, int AHEAD>
@@ -26,16 +26,23 @@ __global__ void __launch_bounds__(WAVES * 64) k(const double* __restrict__ in, d
     static_assert(PER >= 1 && PER * WAVES == KB, "");
     const unsigned lds_base = (unsigned)(uintptr_t)smem;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const long row = blockIdx.x;
+    const int lruns = rot >> 4;                      // log2 of the runs per row
+    const bool skew = (rot >> 2) & 1, perm = (rot >> 3) & 1;
+    const int rmode = rot & 3;
+    long row = blockIdx.x >> lruns;
+    const int run = (int)(blockIdx.x & ((1 << lruns) - 1));
+    if (perm) row = (row * 40503L) % (gridDim.x >> lruns);   // odd multiplier: a permutation of the rows (65536 rows)
     const double* rowp = in + row * 7 * n;
     double* orow = out + row * n;
-    const int steps = (int)(n * 8 / (KB * 1024));
-    const int r0 = rot ? (int)((rot == 1 ? (row >> 3) * 5 + (row & 7) * 3 : (row >> 3)) % steps) : 0;
+    const int steps_row = (int)(n * 8 / (KB * 1024));
+    const int steps = steps_row >> lruns;
+    const int base = run * steps;
+    const int r0 = rmode ? (int)((rmode == 1 ? (row >> 3) * 5 + (row & 7) * 3 : (row >> 3)) % steps) : 0;
     constexpr int SLOT = KB * 1024;
     auto issue = [&](int q) {  // q-th band granule of the run (7 per step)
         const int st = q / 7, b = q % 7;
-        int s = (st + r0) % steps;
-        const int c = ORDER ? s : steps - 1 - s;
+        int s = (st + r0 + (skew ? 5 * b : 0)) % steps;
+        const int c = base + (ORDER ? s : steps - 1 - s);
         const double* src = rowp + (long)b * n + (long)c * (KB * 128);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -57,7 +64,7 @@ __global__ void __launch_bounds__(WAVES * 64) k(const double* __restrict__ in, d
         if (q % 7 == 6) {
             const int st = q / 7;
             int s = (st + r0) % steps;
-            const int c = ORDER ? s : steps - 1 - s;
+            const int c = base + (ORDER ? s : steps - 1 - s);
             double* dst = orow + (long)c * (KB * 128);
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -150,11 +157,12 @@ void run(const double* in, double* out, long rows, long n, size_t lds, int rot) 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(rows), dim3(WAVES * 64), lds, 0, in, out, n, rot);
+    const long grid = rows << (rot >> 4);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, 0, in, out, n, rot);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
     const int reps = 3;
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(rows), dim3(WAVES * 64), lds, 0, in, out, n, rot);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, 0, in, out, n, rot);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -170,14 +178,16 @@ int main(int argc, char** argv) {
     double *in, *out;
     if (hipMalloc(&in, rows * 7 * n * 8) != hipSuccess || hipMalloc(&out, rows * n * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
     hipMemset(in, 0x3c, rows * 7 * n * 8);
-    printf("n = %ld\n", n);
+    printf("n = %ld   (rot: bits 0-1 rotation, 4 band skew, 8 row permutation, >>4 log2 runs per row)\n", n);
     run<1, 4, 0, 3>(in, out, rows, n, 32768, 0);
-    run<1, 4, 0, 3>(in, out, rows, n, 32768, 1);
-    run<1, 4, 0, 3>(in, out, rows, n, 20480, 0);
-    run<4, 16, 0, 3>(in, out, rows, n, 65536, 0);
-    if (n % 2048 == 0) {
-        run_tile<4, 1, 1>(in, out, rows, n, 81920);
-        run_tile<4, 1, 0>(in, out, rows, n, 81920);
-    }
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 4);        // band skew (diagnostic: not what the transform needs)
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 8);        // row permutation
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 16);       // 2 runs per row
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 32);       // 4 runs per row
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 48);       // 8 runs per row
+    run<1, 4, 0, 3>(in, out, rows, n, 32768, 64);       // 16 runs per row
+    run<1, 4, 0, 2>(in, out, rows, n, 32768, 0);        // two bands ahead
+    run<1, 4, 0, 6>(in, out, rows, n, 32768, 0);        // six bands ahead
+    run<1, 4, 0, 6>(in, out, rows, n, 32768, 4);        // six ahead + skew
     return 0;
 }

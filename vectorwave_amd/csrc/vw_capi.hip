@@ -50,6 +50,7 @@ struct PlanOptions {
     int no_ring = 0;                     // 1: bands land in registers (k_inv_blk) instead of the LDS-DMA ring
     int inv_wave = 0;                    // one wavefront per run of 512-sample chunks (k_inv_wave6): 0 = where it pays (large
                                          // batches), -1 = never, N >= 1 = wherever it applies, runs of N chunks
+    int inv_wave_nt = -1;                // k_inv_wave6 loads its bands with the streaming hint: -1 = as the stores (large launches), 0 / 1
     int carry_chunks = 0;                // >= 2: the ring kernel over runs of that many tiles with carried right contexts
                                          // (k_inv_carry); measured 5-7 % slower than one tile per workgroup, so off by default
     int no_wide_inv = 0;                 // 1: long-context inverse never uses the 1024-lane shape
@@ -209,6 +210,8 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_ring = value != 0;
     } else if (strcmp(name, "inv_wave") == 0) {
         o.inv_wave = value > 0 ? static_cast<int>(value < 1000000 ? value : 1000000) : (value < 0 ? -1 : 0);
+    } else if (strcmp(name, "inv_wave_nt") == 0) {
+        o.inv_wave_nt = value < 0 ? -1 : (value != 0);
     } else if (strcmp(name, "carry_chunks") == 0) {
         o.carry_chunks = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_wide_inv") == 0) {
@@ -230,7 +233,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
+                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "inv_wave_nt", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -1117,6 +1120,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                     a.nchunks = static_cast<int32_t>(nch);
                     a.ntiles = static_cast<int32_t>((chunks + nch - 1) / nch);
                     a.ndry = ndry;
+                    a.hoff[0] = ctx->opt.inv_wave_nt >= 0 ? ctx->opt.inv_wave_nt : a.nt_store;
                     nlaunch = b * a.ntiles;
                     if (nlaunch > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
                     carry = false;

@@ -46,8 +46,23 @@ constexpr int wv_slot_w(int J, int j) { return kWvBuf * (1 + ((J - j + 1) & 3));
 
 // The four LDS-DMA instructions of one band chunk: samples [t0, t0 + 512) of `band_row` into the slot at LDS byte
 // address `ldst`, in the layout of the level that reads it (`voff`: the lane's swizzled byte offset inside a 1 KiB block).
+template <bool NT = false>
 __device__ __forceinline__ void wv_issue(const double* __restrict__ band_row, int64_t t0, unsigned voff, unsigned ldst) {
     const double* tsrc = band_row + t0;  // wave-uniform
+    if (NT) {  // the same loads with the streaming hint
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(tsrc), "s"(ldst)
+            : "memory");
+        return;
+    }
     // the instruction's immediate offset is added to the global address AND to the LDS address: one M0, one address
     // register and one offset register serve the four 1 KiB blocks
     unsigned keep;
@@ -321,6 +336,7 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     const int nsteps = ndry + nreal;
     const bool nomath = VW_ABLATED(a, 0);
     const bool noload = VW_ABLATED(a, 1);
+    const bool nt_load = a.hoff[0] != 0;  // bands are read once: load them with the streaming hint
 
     double tl[LT], th[LT];
 #pragma unroll
@@ -365,6 +381,8 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
         if (noload) return;
         if (t0 + kWvSamples > n)
             wv_issue_edge<MODE>(band_row, t0, n, S, lane, lds_base + slot);
+        else if (nt_load)
+            wv_issue<true>(band_row, t0, voff, lds_base + slot);
         else
             wv_issue(band_row, t0, voff, lds_base + slot);
     };
