@@ -1113,7 +1113,9 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                     if (runs > chunks / 16) runs = chunks / 16;
                     if (runs < 1) runs = 1;
                     nch = (chunks + runs - 1) / runs;
-                    if (b * chunks < 4 * want_waves || chunks < 8) wave = false;
+                    // shorter filters leave the tile kernels bound by memory alone, and the tile order streams faster
+                    // (measured on 65536 x 16384, inverse: Haar 11.8 ms ring / 13.8 ms wave, DB2 12.2 / 13.6, DB4 15.7 / 13.8)
+                    if (b * chunks < 4 * want_waves || chunks < 8 || a.lh < 8) wave = false;
                 }
                 if (wave) {
                     a.tiles_per_row = static_cast<int32_t>(chunks);
