@@ -264,7 +264,11 @@ size_t vw_swt_denoise_workspace_bytes(int64_t b, int64_t n, int32_t levels);
  * 8192 x 480, J = 4 streaming block -- never touch the array and are not limited by it.)  Every call on one GPU uses that
  * GPU's one array (whatever the context or stream) and leaves its last contents there: calls that overlap in
  * time on one GPU race and must be ordered by the caller (one stream, or events); nothing in the array needs
- * clearing between calls, every byte a call reads was written by that call. */
+ * clearing between calls, every byte a call reads was written by that call.  Recording the call into a HIP
+ * graph and replaying it on changed input is covered by tests/test_gpu_threads_capture.py.  Cost: the array
+ * takes VW_NOALLOC_SCRATCH_BYTES of device memory on every GPU the process loads the library on, whether or
+ * not this entry point is ever called; if its address cannot be looked up at vw_init the other entry points
+ * work as usual and this one returns VW_E_WORKSPACE for the batches that would need the array. */
 #define VW_NOALLOC_SCRATCH_BYTES ((size_t)160 << 20)
 int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx *ctx, const double *x_dev, int64_t b, int64_t n,
                                          int32_t levels, const double *h, int32_t lh, const double *g,
@@ -440,7 +444,13 @@ int32_t vw_swt_densify_batch_dev(vw_ctx *ctx, const int64_t *offsets_dev, const 
  * 89-122 -> internal/VectorOps.java:448-539) and
  * MutableMultiLevelMODWTResult.applyThreshold
  * (modwt/MutableMultiLevelMODWTResult.java:83-114).  threshold < 0 ->
- * VW_E_NOT_POSITIVE (the reference throws IllegalArgumentException). */
+ * VW_E_NOT_POSITIVE (the reference throws IllegalArgumentException).
+ * NaN coefficients: the soft rule follows the reference's SCALAR form (`|c| <= thr ? 0 : signum(c)(|c| - thr)`,
+ * internal/VectorOps.java:453-460 and the tail loop of the vectorised body), which lets a NaN through.  The
+ * reference is not self-consistent here: its Vector-API body builds the result from `c > thr` / `c < -thr`
+ * masks (:475-477), both false for a NaN, and writes 0.0 for those lanes.  For lengths the reference
+ * vectorises, NaN handling is therefore unpinned; finite inputs are unaffected.  The same holds for
+ * vw_wavelet_denoise_batch (WaveletDenoiser with useVectorOps). */
 int32_t vw_threshold(vw_ctx *ctx, const double *in, int64_t count, double threshold, int32_t soft,
                      double *out);
 int32_t vw_threshold_dev(vw_ctx *ctx, const double *in_dev, int64_t count, double threshold,

@@ -112,3 +112,36 @@ def test_mirror_api_and_errors(ctx):
     yb = den.denoiseMultiLevelBatch(xs, 4, ThresholdMethod.BAYES, ThresholdType.HARD)
     for i in range(5):
         assert np.array_equal(yb[i], den.denoiseMultiLevel(xs[i], 4, ThresholdMethod.BAYES, ThresholdType.HARD))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [480, 6000])
+def test_undersized_workspace_is_refused_whatever_the_row_length(ctx, n):
+    """A caller-supplied workspace smaller than vw_wavelet_denoise_workspace_bytes is an error for short rows (which the
+    single-launch kernels would serve without touching it) exactly as for long ones; a workspace of the right size, or
+    none, works."""
+    import ctypes as C
+    import math
+    import torch
+    from util import _dp, _t, signals
+    w = get_wavelet("db4")
+    h, g, hr, gr = _t(w.dec_lo), _t(w.dec_hi), _t(w.rec_lo), _t(w.rec_hi)
+    b, levels = 6, 4
+    x_t = torch.from_numpy(signals(b, n, seed=n)).cuda()
+    out = torch.empty((b, n), dtype=torch.float64, device="cuda")
+    thr = torch.empty((b, levels), dtype=torch.float64, device="cuda")
+    need = ctx.lib.vw_wavelet_denoise_workspace_bytes(b, n, levels)
+    ws = torch.empty((need + 7) // 8, dtype=torch.float64, device="cuda")
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(ws_ptr, ws_bytes):
+        return ctx.lib.vw_wavelet_denoise_batch_dev(ctx.handle, C.c_void_p(x_t.data_ptr()), b, n, levels, _dp(h), h.size, _dp(g), g.size,
+                                                    _dp(hr), hr.size, _dp(gr), gr.size, 0, 0, 0, 1, 0.0, math.log(n),
+                                                    C.c_void_p(out.data_ptr()), C.c_void_p(thr.data_ptr()), ws_ptr, ws_bytes, sp)
+
+    assert call(C.c_void_p(ws.data_ptr()), need - 8) == N.VW_E_WORKSPACE
+    assert "needed" in ctx.last_error()
+    assert call(C.c_void_p(ws.data_ptr()), need) == N.VW_OK, ctx.last_error()
+    a = out.cpu().numpy().copy()
+    assert call(None, 0) == N.VW_OK, ctx.last_error()
+    assert_bits_equal(out.cpu().numpy(), a, "caller's workspace vs the context's")

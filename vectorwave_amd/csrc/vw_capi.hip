@@ -283,12 +283,10 @@ extern "C" int32_t vw_init(int32_t device, vw_ctx** out_ctx) {
         snprintf(ctx->info, sizeof(ctx->info), "HIP device %d", device);
     }
     strcpy(ctx->err, "no error");
+    // the static array behind the allocation-free entry point.  A failed lookup is not fatal: every other entry point
+    // works without it, and vw_swt_denoise_batch_noalloc_dev then reports VW_E_WORKSPACE for the batches that need it
     void* scratch = nullptr;
-    if (scratch_lookup(device, &scratch) != VW_OK) {  // `device` is current here
-        (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return VW_E_HIP;
-    }
+    if (scratch_lookup(device, &scratch) != VW_OK) scratch = nullptr;  // `device` is current here
     ctx->scratch = scratch;
 #ifdef VW_TUNING
     tuning_env(ctx);
@@ -1623,6 +1621,10 @@ extern "C" int32_t vw_swt_denoise_batch_noalloc_dev(vw_ctx* ctx, const double* x
                        "batch of %lld x %lld samples at %d levels needs %zu bytes of scratch; the allocation-free entry point "
                        "holds %zu (VW_NOALLOC_SCRATCH_BYTES): split the batch or use vw_swt_denoise_batch_dev",
                        static_cast<long long>(b), static_cast<long long>(n), levels, need, kScratchBytes);
+    if (ctx->scratch == nullptr)
+        return set_err(ctx, VW_E_WORKSPACE,
+                       "the static scratch array of the allocation-free entry point could not be located on device %d "
+                       "(hipGetSymbolAddress failed in vw_init): use vw_swt_denoise_batch_dev", ctx->device);
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
     char* base = static_cast<char*>(ctx->scratch);  // device address of this GPU's array, never the symbol itself
@@ -1854,6 +1856,11 @@ extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     VW_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // a workspace the caller passes must be large enough whichever kernels the plan takes (the short-row kernels below
+    // would not touch it): the error contract does not depend on the row length
+    const size_t need = vw_wavelet_denoise_workspace_bytes(b, n, levels);
+    if (workspace_dev != nullptr && workspace_bytes < need)
+        return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
     // short rows, rules that are functions of sigma alone (or a fixed threshold): the single-launch row kernels, in the
     // reference's arithmetic only
     if (!(flags & VW_FLAG_FMA) && row_denoise_eligible(ctx, n, levels, lh, lg, lhr, lgr, boundary) &&
@@ -1869,10 +1876,8 @@ extern "C" int32_t vw_wavelet_denoise_batch_dev(vw_ctx* ctx, const double* x_dev
         return row_denoise_dev(ctx, x_dev, b, n, levels, h, lh, g, hr, gr, boundary, fixed ? fixed_threshold : -1.0, 0.0,
                                soft ? 3 : 2, y_dev, thresholds_out_dev, s, rr);
     }
-    const size_t need = vw_wavelet_denoise_workspace_bytes(b, n, levels);
     char* wsb;
     if (workspace_dev != nullptr) {
-        if (workspace_bytes < need) return set_err(ctx, VW_E_WORKSPACE, "workspace of %zu bytes given, %zu needed", workspace_bytes, need);
         wsb = static_cast<char*>(workspace_dev);
     } else {
         rc = ensure(ctx, ctx->denoise_ws, need);
