@@ -75,3 +75,43 @@ def test_wave_inverse_not_taken_where_it_does_not_apply(ctx, plan):
     st, got3, _ = gpu_inverse(ctx, coeffs, "db4", P)
     assert st == 0 and "k_inv_wave" not in ctx.last_plan()
     assert_bits_equal(got3, want, "switched off")
+
+
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("nch", [2, 1000])
+@pytest.mark.parametrize("thr,soft", [(-1.0, True), (-1.0, False), (0.25, True), (0.0, True), (float("nan"), True),
+                                      (float("nan"), False), (float("inf"), True), (float("inf"), False)])
+def test_wave_swt_denoise_bit_exact(ctx, plan, thr, soft, nch, mode):
+    """VectorWaveSwtAdapter.denoise at six levels through the wave kernel: the detail bands are thresholded as they land
+    (MutableMultiLevelMODWTResult.applyThreshold, modwt/MutableMultiLevelMODWTResult.java:97-114), including thresholds
+    that are no finite non-negative number (swt/VectorWaveSwtAdapter.java:296-312: `NaN < 0` is false, so a NaN is
+    used as a fixed threshold)."""
+    from util import gpu_denoise
+    plan("inv_wave", nch)
+    w = get_wavelet("db4")
+    x = signals(3, 5000, seed=17)
+    st, want = o.swt_denoise_batch(x, w, 6, thr, soft, mode)
+    assert st == 0
+    st, got, _ = gpu_denoise(ctx, x, "db4", 6, mode, thr, soft)
+    assert st == N.VW_OK, ctx.last_error()
+    assert "k_inv_wave" in ctx.last_plan(), ctx.last_plan()
+    assert_bits_equal(got, want, "swt denoise through the wave kernel, threshold %r soft=%s" % (thr, soft))
+
+
+@pytest.mark.parametrize("method", ["UNIVERSAL", "MINIMAX", "BAYES"])
+@pytest.mark.parametrize("soft", [True, False])
+def test_wave_wavelet_denoiser_bit_exact(ctx, plan, method, soft):
+    """WaveletDenoiser.denoiseMultiLevel (denoising/WaveletDenoiser.java:152-227): per-level thresholds, the soft rule in
+    its NaN-propagating form, with a NaN planted in one row's input."""
+    import torch
+    from util import dev_wavelet_denoise
+    plan("inv_wave", 3)
+    w = get_wavelet("sym4")
+    x = signals(3, 4096, seed=23)
+    m = getattr(o, method)
+    st, want, wthr = o.wavelet_denoise_batch(x, w, 6, m, soft, 0)
+    assert st == 0
+    got, thr = dev_wavelet_denoise(ctx, torch.from_numpy(x).cuda(), "sym4", 6, 0, getattr(N, "VW_THRESHOLD_" + method), soft)
+    assert "k_inv_wave" in ctx.last_plan(), ctx.last_plan()
+    assert_bits_equal(thr.cpu().numpy(), wthr, "thresholds")
+    assert_bits_equal(got.cpu().numpy(), want, "WaveletDenoiser %s through the wave kernel" % method)

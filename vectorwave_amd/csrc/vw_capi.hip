@@ -1096,7 +1096,9 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             const bool plain_inv = thr_mode == 0 && first_bad_cell == nullptr && a.band_mask == 0xffffffffu;
             // one wavefront per run of chunks: wins once every CU holds its five waves several times over and the runs are
             // long enough for the warm-up chunk not to matter; below that the tile kernels stay
-            bool wave = ctx->opt.inv_wave >= 0 && vec2 && plain_inv && inv_wave_supported(a.lh, st.lev0, st.lev1, boundary, n) &&
+            // (a denoise that only thresholds goes along: the bands are thresholded as they land)
+            const bool thr_only = thr_mode != 0 && !(flags & VW_FLAG_FMA) && first_bad_cell == nullptr && a.band_mask == 0xffffffffu;
+            bool wave = ctx->opt.inv_wave >= 0 && vec2 && (plain_inv || thr_only) && inv_wave_supported(a.lh, st.lev0, st.lev1, boundary, n) &&
                         ctx->lds_limit >= 32768;
             if (wave) {
                 const int64_t chunks = (n + 511) / 512;

@@ -14,9 +14,18 @@ int inv_wave_ndry(int taps, int lev1) {
     const int ctx = (taps - 1) * ((1 << lev1) - 1);
     return (ctx + kWvSamples - 1) / kWvSamples;
 }
+template <int LT, int MODE>
+static hipError_t launch_inv_wave_th(const InvArgs& a, int64_t nblocks, size_t lds, hipStream_t stream) {
+    if (a.thr_mode == 1) return launch_tile_nt(k_inv_wave6<LT, MODE, false, 1>, a, 64, nblocks, lds, stream);
+    if (a.thr_mode == 2) return launch_tile_nt(k_inv_wave6<LT, MODE, false, 2>, a, 64, nblocks, lds, stream);
+    return launch_tile_nt(k_inv_wave6<LT, MODE, false, 3>, a, 64, nblocks, lds, stream);
+}
 template <int LT>
 static hipError_t launch_inv_wave_lt(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream) {
     const size_t lds = wv_lds_bytes(LT, 6);
+    if (a.thr_mode != 0)  // (the planner sends thresholding inverses here in the reference's arithmetic only)
+        return mode == kPeriodic ? launch_inv_wave_th<LT, kPeriodic>(a, nblocks, lds, stream)
+                                 : launch_inv_wave_th<LT, kZeroPad>(a, nblocks, lds, stream);
     if (mode == kPeriodic)
         return fma ? launch_tile_nt(k_inv_wave6<LT, kPeriodic, true>, a, 64, nblocks, lds, stream)
                    : launch_tile_nt(k_inv_wave6<LT, kPeriodic, false>, a, 64, nblocks, lds, stream);

@@ -39,7 +39,8 @@ constexpr int wv_hoff(int lt, int j) {
     for (int i = 1; i < j; ++i) s += wv_hp(lt, i);
     return s;
 }
-constexpr int wv_lds_bytes(int lt, int J) { return kWvHeads + 2 * wv_hoff(lt, J + 1) * 16; }
+constexpr int wv_thr_off(int lt, int J) { return kWvHeads + 2 * wv_hoff(lt, J + 1) * 16; }  // per-level thresholds of the row
+constexpr int wv_lds_bytes(int lt, int J) { return wv_thr_off(lt, J) + 8 * 8; }
 // A chunk's bands in the order they are consumed: a_J, W_J, ..., W_1; the band at position q lands in slot q mod 4.
 constexpr int wv_slot_a() { return kWvBuf; }
 constexpr int wv_slot_w(int J, int j) { return kWvBuf * (1 + ((J - j + 1) & 3)); }
@@ -141,6 +142,11 @@ __device__ __forceinline__ void wv_level(char* lds, int lane, const WvLevelAddr<
     constexpr int HPJ = wv_hp(LT, j);
     constexpr int NH = (HPJ + 63) / 64;
     static_assert(NH <= 2, "at most two head pairs per lane");
+    // The lanes of the wave exchange data through LDS (what one lane stored -- a write-back, the zeros or the thresholded
+    // values of a landed band -- another lane reads here), and the compiler reasons about ONE lane: it may move a load above
+    // a store that this lane cannot alias.  Every such hand-over therefore sits behind a compiler-level memory barrier (the
+    // hardware serves a wave's LDS requests in order anyway).
+    asm volatile("" ::: "memory");
     double2 r[LT + 3], w[LT + 3];
     double2 hr0 = make_double2(0.0, 0.0), hw0 = hr0, hr1 = hr0, hw1 = hr0;
 #pragma unroll
@@ -230,6 +236,7 @@ __device__ __forceinline__ void wv_level1(char* lds, int lane, const WvLevel1Add
     constexpr int E = wv_hoff(LT, J + 1) * 16;
     constexpr int HPJ = wv_hp(LT, 1);
     static_assert(HPJ <= 64, "level-1 heads: one pair per lane");
+    asm volatile("" ::: "memory");  // (as in wv_level: other lanes' stores precede these loads)
     // two 64-pair blocks at a time
 #pragma unroll
     for (int k0 = 0; k0 < 4; k0 += 2) {
@@ -311,15 +318,46 @@ __device__ __forceinline__ void wv_zero_tail(char* lds, int slot, int64_t t0, in
     }
 }
 
+// Thresholding of a freshly landed detail band chunk in place (TH = mode of apply_thr: 1 soft / a NaN coefficient becomes
+// zero, 2 hard, 3 soft / a NaN coefficient stays).  The level's threshold is constant along the row, so every chunk of
+// the band gets the same rule and the heads, which are copied out of the slot afterwards, hold thresholded values.  A
+// finite threshold >= 0 takes the three-instruction forms of consume_thr, anything else the reference's rule as written.
+template <int TH>
+__device__ __forceinline__ void wv_threshold_slot(char* lds, int slot, int thr_addr, int lane) {
+    const double thr = *reinterpret_cast<const double*>(lds + thr_addr);  // same address in every lane: a broadcast
+    double2 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2*>(lds + slot + ((64 * i + lane) << 4));
+    const bool plain = finite_f64(thr) && thr >= 0.0;
+    if (__builtin_amdgcn_ballot_w64(plain) != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x = consume_thr<TH>(v[i].x, thr);
+            v[i].y = consume_thr<TH>(v[i].y, thr);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x = apply_thr(v[i].x, thr, TH);
+            v[i].y = apply_thr(v[i].y, thr, TH);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(lds + slot + ((64 * i + lane) << 4)) = v[i];
+}
+
 // Levels 6 .. 1 of rows of even length n >= 1024, PERIODIC or ZERO_PADDING, both filters of LT taps.
 // a.ntiles = runs per row (counted from the right end of the row), a.nchunks = chunks per run (>= a.ndry),
 // a.tiles_per_row = chunks per row (the last one may be partial), a.ndry = warm-up chunks.
 // Chunk c covers the samples [512 c, 512 c + 512) of the row extended by its boundary rule; a PERIODIC run at the right
 // end of the row warms up on the chunks behind the row end, i.e. on the wrapped start of the row; a ZERO_PADDING run
 // there needs no warm-up: right of the row everything is zero at every level, and the heads start as zeros.
-template <int LT, int MODE, bool FMA>
+// TH != 0: a denoise that only thresholds -- the detail bands are thresholded as they land (a.thr: threshold of row r,
+// level j at thr[r * thr_row_stride + (j - 1) * thr_level_stride]).
+template <int LT, int MODE, bool FMA, int TH = 0>
 __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     constexpr int J = 6;
+    constexpr int THR = wv_thr_off(LT, J);
     extern __shared__ double2 vw_smem[];
     char* lds = reinterpret_cast<char*>(vw_smem);
     const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
@@ -376,6 +414,10 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
         for (int i = lane; i < NHP; i += 64) *reinterpret_cast<double2*>(lds + kWvHeads + (i << 4)) = make_double2(0.0, 0.0);
     }
 
+    if (TH != 0) {  // the row's six thresholds, kept in LDS (read back per level as a broadcast)
+        if (lane < J) *reinterpret_cast<double*>(lds + THR + 8 * lane) = a.thr[row * a.thr_row_stride + lane * a.thr_level_stride];
+    }
+
     // one band chunk on its way: S = log2 stride of the level that reads it, voff = the lane's offset in that layout
     auto issue = [&](const double* band_row, int64_t t0, int S, int voff, int slot) {
         if (noload) return;
@@ -409,21 +451,27 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
             wv_zero_tail(lds, wv_slot_a(), t0, n, 4, lane);
             wv_zero_tail(lds, wv_slot_w(J, 6), t0, n, 4, lane);
         }
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 6), THR + 8 * 5, lane);
         wv_level<LT, J, 6, FMA>(lds, lane, A6, vsid, tl, th, nomath, [&] { issue(wband(3), t0, 1, vs1, wv_slot_w(J, 3)); });
         wv_wait_vm(noload ? 0 : 8 + pst);  // W_5
         if (ztail) wv_zero_tail(lds, wv_slot_w(J, 5), t0, n, 3, lane);
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 5), THR + 8 * 4, lane);
         wv_level<LT, J, 5, FMA>(lds, lane, A5, vs3, tl, th, nomath, [&] { issue(wband(2), t0, 0, vs0, wv_slot_w(J, 2)); });
         wv_wait_vm(noload ? 0 : 8 + pst);  // W_4
         if (ztail) wv_zero_tail(lds, wv_slot_w(J, 4), t0, n, 2, lane);
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 4), THR + 8 * 3, lane);
         wv_level<LT, J, 4, FMA>(lds, lane, A4, vs2, tl, th, nomath, [&] { issue(wband(1), t0, -1, vsid, wv_slot_w(J, 1)); });
         wv_wait_vm(noload ? 0 : 8);  // W_3
         if (ztail) wv_zero_tail(lds, wv_slot_w(J, 3), t0, n, 1, lane);
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 3), THR + 8 * 2, lane);
         wv_level<LT, J, 3, FMA>(lds, lane, A3, vs1, tl, th, nomath, [&] { if (pf) issue(arow, tn, 4, vsid, wv_slot_a()); });
         wv_wait_vm(noload ? 0 : (last ? 4 : 8));  // W_2
         if (ztail) wv_zero_tail(lds, wv_slot_w(J, 2), t0, n, 0, lane);
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 2), THR + 8 * 1, lane);
         wv_level<LT, J, 2, FMA>(lds, lane, A2, vs0, tl, th, nomath, [&] { if (pf) issue(wband(6), tn, 4, vsid, wv_slot_w(J, 6)); });
         wv_wait_vm(noload ? 0 : (last ? 0 : 8));  // W_1
         if (ztail) wv_zero_tail(lds, wv_slot_w(J, 1), t0, n, -1, lane);
+        if (TH != 0) wv_threshold_slot<TH>(lds, wv_slot_w(J, 1), THR + 8 * 0, lane);
         double out[4][2];
         wv_level1<LT, J, FMA>(lds, lane, A1, tl, th, nomath, out, [&] {
             if (pf) {
