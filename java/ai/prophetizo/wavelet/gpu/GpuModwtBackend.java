@@ -10,6 +10,7 @@ import java.lang.foreign.Arena;
 import java.lang.foreign.MemorySegment;
 import java.util.ArrayDeque;
 import java.util.concurrent.ConcurrentHashMap;
+import java.util.concurrent.atomic.AtomicBoolean;
 
 import static java.lang.foreign.ValueLayout.ADDRESS;
 import static java.lang.foreign.ValueLayout.JAVA_DOUBLE;
@@ -24,15 +25,25 @@ import static java.lang.foreign.ValueLayout.JAVA_LONG;
  * <p>Signal and coefficient staging buffers are page-locked (vw_host_alloc) and reused from a small pool, so
  * that the copies to and from the GPU run by DMA at the PCIe rate; only the few filter taps and scalar
  * outputs come from a confined Arena.
+ *
+ * <p>Batches of any size: coefficients travel as one {@code double[]} of (J+1)*N values per signal, and a call is
+ * cut into row chunks so that no staging request exceeds {@code vectorwave.gpu.stagingBytes} (system property,
+ * default 1 GiB) and no flat index exceeds what a Java array or a 32-bit int can hold.  The 65536 x 16384, J = 6
+ * batch (7.5e9 coefficients) is 57 downcalls of 1149 rows at the default.
  */
 public final class GpuModwtBackend implements AutoCloseable {
     private static final ConcurrentHashMap<Integer, GpuModwtBackend> SHARED = new ConcurrentHashMap<>();
 
     private final MemorySegment ctx;
+    private final int device;
     private final ArrayDeque<MemorySegment> freeStaging = new ArrayDeque<>();
-    private volatile boolean closed;
+    private final AtomicBoolean closed = new AtomicBoolean();
+    /** staging segments handed out and not yet given back; the context is destroyed when the last one returns */
+    private int outstanding;
+    private boolean destroyed;
 
     public GpuModwtBackend(int device) {
+        this.device = device;
         this.ctx = VwGpuNative.init(device);
     }
 
@@ -43,7 +54,24 @@ public final class GpuModwtBackend implements AutoCloseable {
      */
     public static GpuModwtBackend shared() {
         int device = Integer.getInteger("vectorwave.gpu.device", 0);
-        return SHARED.computeIfAbsent(device, GpuModwtBackend::new);
+        // a backend that somebody closed is replaced, not handed out again
+        return SHARED.compute(device, (d, cur) -> (cur == null || cur.closed.get()) ? new GpuModwtBackend(d) : cur);
+    }
+
+    /** Largest staging request of one downcall, in bytes (system property vectorwave.gpu.stagingBytes, default 1 GiB). */
+    static long stagingCap() {
+        return Math.max(1L << 16, Long.getLong("vectorwave.gpu.stagingBytes", 1L << 30));
+    }
+
+    /**
+     * Rows per downcall for rows of {@code inPerRow} input and {@code outPerRow} output values: within the staging cap
+     * and with every flat element index of a chunk below Integer.MAX_VALUE - 8 (the largest Java array).
+     */
+    static int rowsPerCall(long inPerRow, long outPerRow, int rows) {
+        long perRowBytes = Math.max(1, (inPerRow + outPerRow) * Double.BYTES);
+        long byBytes = Math.max(1, stagingCap() / perRowBytes);
+        long byIndex = Math.max(1, (Integer.MAX_VALUE - 8L) / Math.max(1, Math.max(inPerRow, outPerRow)));
+        return (int) Math.max(1, Math.min(rows, Math.min(byBytes, byIndex)));
     }
 
     /** vw_performance_info of this backend's context. */
@@ -65,6 +93,10 @@ public final class GpuModwtBackend implements AutoCloseable {
     /** A page-locked segment of at least {@code bytes} bytes; give it back with {@link #release}. */
     private MemorySegment acquire(long bytes) {
         synchronized (freeStaging) {
+            if (closed.get()) {
+                throw new IllegalStateException("GpuModwtBackend of device " + device + " is closed");
+            }
+            outstanding++;
             for (var it = freeStaging.iterator(); it.hasNext(); ) {
                 MemorySegment s = it.next();
                 if (s.byteSize() >= bytes) {
@@ -73,34 +105,59 @@ public final class GpuModwtBackend implements AutoCloseable {
                 }
             }
         }
-        // sizes rounded up to a power of two (at least 64 KiB) so that repeated calls of similar size share buffers
-        long cap = Math.max(1L << 16, Long.highestOneBit(Math.max(bytes, 1) - 1) << 1);
-        return VwGpuNative.hostAlloc(ctx, cap);
+        try {
+            // sizes rounded up to a power of two (at least 64 KiB) so that repeated calls of similar size share buffers
+            long cap = Math.max(1L << 16, Long.highestOneBit(Math.max(bytes, 1) - 1) << 1);
+            return VwGpuNative.hostAlloc(ctx, cap);
+        } catch (RuntimeException | Error e) {
+            synchronized (freeStaging) {
+                outstanding--;
+            }
+            throw e;
+        }
     }
 
     private void release(MemorySegment s) {
+        boolean destroyNow;
         synchronized (freeStaging) {
-            if (!closed && freeStaging.size() < 8) {
+            outstanding--;
+            if (!closed.get() && freeStaging.size() < 8) {
                 freeStaging.addFirst(s);
                 return;
             }
+            destroyNow = closed.get() && outstanding == 0 && !destroyed;
+            if (destroyNow) {
+                destroyed = true;
+            }
         }
-        VwGpuNative.hostFree(ctx, s);
+        VwGpuNative.hostFree(ctx, s);  // the context is still alive: it is destroyed only below, after the last segment
+        if (destroyNow) {
+            destroyContext();
+        }
     }
 
-    private static void pack(MemorySegment seg, double[][] rows, int n) {
-        for (int b = 0; b < rows.length; b++) {
+    private void destroyContext() {
+        try {
+            int ignored = (int) VwGpuNative.VW_DESTROY.invokeExact(ctx);
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
+    /** Rows [r0, r1) of a batch into a segment, row-major. */
+    private static void pack(MemorySegment seg, double[][] rows, int r0, int r1, int n) {
+        for (int b = r0; b < r1; b++) {
             if (rows[b].length != n) {
                 throw new InvalidArgumentException(ErrorCode.VAL_LENGTH_MISMATCH,
-                    "Row " + b + " has " + rows[b].length + " samples, the batch has " + n);
+                    "Row " + b + " has " + rows[b].length + " values, the batch has " + n);
             }
-            MemorySegment.copy(rows[b], 0, seg, JAVA_DOUBLE, (long) b * n * Double.BYTES, n);
+            MemorySegment.copy(rows[b], 0, seg, JAVA_DOUBLE, (long) (b - r0) * n * Double.BYTES, n);
         }
     }
 
-    private static void unpack(MemorySegment seg, double[][] rows, int n) {
-        for (int b = 0; b < rows.length; b++) {
-            MemorySegment.copy(seg, JAVA_DOUBLE, (long) b * n * Double.BYTES, rows[b], 0, n);
+    private static void unpack(MemorySegment seg, double[][] rows, int r0, int r1, int n) {
+        for (int b = r0; b < r1; b++) {
+            MemorySegment.copy(seg, JAVA_DOUBLE, (long) (b - r0) * n * Double.BYTES, rows[b], 0, n);
         }
     }
 
@@ -146,30 +203,39 @@ public final class GpuModwtBackend implements AutoCloseable {
      * J-level forward of B equal-length signals.  levels == 1 with singleLevel == true is
      * MODWTTransform.forwardBatch; otherwise MultiLevelMODWTTransform.decompose applied per row.
      *
-     * @return coefficients [B][J+1][N] flattened
+     * @return one block of (J+1)*N coefficients per signal, ordered d_1..d_J, a_J
      */
-    public double[] forward(double[][] signals, Wavelet w, BoundaryMode mode, int levels, boolean singleLevel,
-                            boolean checkFinite) {
+    public double[][] forward(double[][] signals, Wavelet w, BoundaryMode mode, int levels, boolean singleLevel,
+                              boolean checkFinite) {
         int b = signals.length;
         int n = b == 0 ? 0 : signals[0].length;
-        double[] out = new double[Math.multiplyExact(Math.multiplyExact(b, levels + 1), n)];
+        int perRow = Math.multiplyExact(levels + 1, n);  // one signal's block must fit a Java array, as in the reference
+        double[][] out = new double[b][perRow];
         if (b == 0) {
             return out;
         }
-        long xBytes = (long) b * n * Double.BYTES;
-        MemorySegment stage = acquire(xBytes + (long) out.length * Double.BYTES);
+        int step = rowsPerCall(n, perRow, b);
+        double[] h = w.lowPassDecomposition();
+        double[] g = w.highPassDecomposition();
+        int flags = (singleLevel ? VwGpuNative.FLAG_SINGLE_LEVEL : 0) | (checkFinite ? VwGpuNative.FLAG_CHECK_FINITE : 0);
+        MemorySegment stage = acquire((long) step * (n + (long) perRow) * Double.BYTES);
         try (Arena a = Arena.ofConfined()) {
-            MemorySegment x = stage.asSlice(0, xBytes);
-            MemorySegment c = stage.asSlice(xBytes, (long) out.length * Double.BYTES);
-            pack(x, signals, n);
+            MemorySegment th = taps(a, h);
+            MemorySegment tg = taps(a, g);
             MemorySegment bad = a.allocate(JAVA_LONG);
-            double[] h = w.lowPassDecomposition();
-            double[] g = w.highPassDecomposition();
-            int flags = (singleLevel ? VwGpuNative.FLAG_SINGLE_LEVEL : 0) | (checkFinite ? VwGpuNative.FLAG_CHECK_FINITE : 0);
-            int st = (int) VwGpuNative.VW_MODWT_FORWARD_BATCH.invokeExact(ctx, x, (long) b, (long) n, levels, taps(a, h),
-                h.length, taps(a, g), g.length, boundary(mode), flags, c, bad);
-            check(st, bad.get(JAVA_LONG, 0));
-            MemorySegment.copy(c, JAVA_DOUBLE, 0, out, 0, out.length);
+            for (int r0 = 0; r0 < b; r0 += step) {
+                int r1 = Math.min(b, r0 + step);
+                long xBytes = (long) (r1 - r0) * n * Double.BYTES;
+                long cBytes = (long) (r1 - r0) * perRow * Double.BYTES;
+                MemorySegment x = stage.asSlice(0, xBytes);
+                MemorySegment c = stage.asSlice((long) step * n * Double.BYTES, cBytes);
+                pack(x, signals, r0, r1, n);
+                int st = (int) VwGpuNative.VW_MODWT_FORWARD_BATCH.invokeExact(ctx, x, (long) (r1 - r0), (long) n, levels, th,
+                    h.length, tg, g.length, boundary(mode), flags, c, bad);
+                long firstBad = bad.get(JAVA_LONG, 0);
+                check(st, firstBad < 0 ? firstBad : firstBad + (long) r0 * n);  // flat index of the whole batch
+                unpack(c, out, r0, r1, perRow);
+            }
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -181,40 +247,51 @@ public final class GpuModwtBackend implements AutoCloseable {
     }
 
     /**
-     * Inverse of {@link #forward}: coefficients [B][J+1][N] -> signals [B][N].  bandMask == -1 uses every band;
-     * otherwise band k of the block counts as zeros unless bit k is set (bit 0 = d_1 .. bit J-1 = d_J, bit J = a_J):
-     * reconstructFromLevel / reconstructLevels / extractLevel without zeroed copies.
+     * Inverse of {@link #forward}: one block of (J+1)*N coefficients per signal -> signals [B][N].  bandMask == -1 uses
+     * every band; otherwise band k of the block counts as zeros unless bit k is set (bit 0 = d_1 .. bit J-1 = d_J,
+     * bit J = a_J): reconstructFromLevel / reconstructLevels / extractLevel without zeroed copies.
      */
-    public double[][] inverse(double[] coeffs, int b, int n, Wavelet w, BoundaryMode mode, int levels,
+    public double[][] inverse(double[][] coeffs, int n, Wavelet w, BoundaryMode mode, int levels,
                               boolean singleLevel, boolean batchVariant, int bandMask) {
+        int b = coeffs.length;
+        int perRow = Math.multiplyExact(levels + 1, n);
         double[][] out = new double[b][n];
         if (b == 0) {
             return out;
         }
-        long cBytes = (long) coeffs.length * Double.BYTES;
-        long xBytes = (long) b * n * Double.BYTES;
-        MemorySegment stage = acquire(cBytes + xBytes);
+        int step = rowsPerCall(perRow, n, b);
+        double[] hr = w.lowPassReconstruction();
+        double[] gr = w.highPassReconstruction();
+        MemorySegment stage = acquire((long) step * (n + (long) perRow) * Double.BYTES);
         try (Arena a = Arena.ofConfined()) {
-            MemorySegment c = stage.asSlice(0, cBytes);
-            MemorySegment x = stage.asSlice(cBytes, xBytes);
-            MemorySegment.copy(coeffs, 0, c, JAVA_DOUBLE, 0, coeffs.length);
-            double[] hr = w.lowPassReconstruction();
-            double[] gr = w.highPassReconstruction();
-            int st;
-            long firstBad = -1;
-            if (bandMask == -1) {
-                MemorySegment bad = a.allocate(JAVA_LONG);
-                int flags = (singleLevel ? VwGpuNative.FLAG_SINGLE_LEVEL : 0)
-                    | (batchVariant ? VwGpuNative.FLAG_SYMMETRIC_BATCH_VARIANT : 0);
-                st = (int) VwGpuNative.VW_MODWT_INVERSE_BATCH.invokeExact(ctx, c, (long) b, (long) n, levels, taps(a, hr),
-                    hr.length, taps(a, gr), gr.length, boundary(mode), flags, x, bad);
-                firstBad = bad.get(JAVA_LONG, 0);
-            } else {
-                st = (int) VwGpuNative.VW_MODWT_INVERSE_BANDS_BATCH.invokeExact(ctx, c, (long) b, (long) n, levels,
-                    taps(a, hr), hr.length, taps(a, gr), gr.length, boundary(mode), bandMask, x);
+            MemorySegment thr = taps(a, hr);
+            MemorySegment tgr = taps(a, gr);
+            MemorySegment bad = a.allocate(JAVA_LONG);
+            for (int r0 = 0; r0 < b; r0 += step) {
+                int r1 = Math.min(b, r0 + step);
+                long cBytes = (long) (r1 - r0) * perRow * Double.BYTES;
+                long xBytes = (long) (r1 - r0) * n * Double.BYTES;
+                MemorySegment c = stage.asSlice(0, cBytes);
+                MemorySegment x = stage.asSlice((long) step * perRow * Double.BYTES, xBytes);
+                pack(c, coeffs, r0, r1, perRow);
+                int st;
+                long firstBad = -1;
+                if (bandMask == -1) {
+                    int flags = (singleLevel ? VwGpuNative.FLAG_SINGLE_LEVEL : 0)
+                        | (batchVariant ? VwGpuNative.FLAG_SYMMETRIC_BATCH_VARIANT : 0);
+                    st = (int) VwGpuNative.VW_MODWT_INVERSE_BATCH.invokeExact(ctx, c, (long) (r1 - r0), (long) n, levels, thr,
+                        hr.length, tgr, gr.length, boundary(mode), flags, x, bad);
+                    firstBad = bad.get(JAVA_LONG, 0);
+                    if (firstBad >= 0) {
+                        firstBad += (long) r0 * perRow;
+                    }
+                } else {
+                    st = (int) VwGpuNative.VW_MODWT_INVERSE_BANDS_BATCH.invokeExact(ctx, c, (long) (r1 - r0), (long) n, levels,
+                        thr, hr.length, tgr, gr.length, boundary(mode), bandMask, x);
+                }
+                check(st, firstBad);
+                unpack(x, out, r0, r1, n);
             }
-            check(st, firstBad);
-            unpack(x, out, n);
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -234,23 +311,32 @@ public final class GpuModwtBackend implements AutoCloseable {
         if (b == 0) {
             return out;
         }
-        long xBytes = (long) b * n * Double.BYTES;
-        MemorySegment stage = acquire(2 * xBytes);
+        int step = rowsPerCall(n, n, b);
+        double[] h = w.lowPassDecomposition();
+        double[] g = w.highPassDecomposition();
+        double[] hr = w.lowPassReconstruction();
+        double[] gr = w.highPassReconstruction();
+        // the transcendental stays on the JVM so the threshold matches Math.sqrt(2 * Math.log(n)) bit for bit
+        double sqrt2lnN = Math.sqrt(2 * Math.log(n));
+        long half = (long) step * n * Double.BYTES;
+        MemorySegment stage = acquire(2 * half);
         try (Arena a = Arena.ofConfined()) {
-            MemorySegment x = stage.asSlice(0, xBytes);
-            MemorySegment y = stage.asSlice(xBytes, xBytes);
-            pack(x, signals, n);
-            double[] h = w.lowPassDecomposition();
-            double[] g = w.highPassDecomposition();
-            double[] hr = w.lowPassReconstruction();
-            double[] gr = w.highPassReconstruction();
-            // the transcendental stays on the JVM so the threshold matches Math.sqrt(2 * Math.log(n)) bit for bit
-            double sqrt2lnN = Math.sqrt(2 * Math.log(n));
-            int st = (int) VwGpuNative.VW_SWT_DENOISE_BATCH.invokeExact(ctx, x, (long) b, (long) n, levels, taps(a, h),
-                h.length, taps(a, g), g.length, taps(a, hr), hr.length, taps(a, gr), gr.length, boundary(mode), threshold,
-                sqrt2lnN, soft ? 1 : 0, y, MemorySegment.NULL);
-            check(st, -1);
-            unpack(y, out, n);
+            MemorySegment th = taps(a, h);
+            MemorySegment tg = taps(a, g);
+            MemorySegment thr = taps(a, hr);
+            MemorySegment tgr = taps(a, gr);
+            for (int r0 = 0; r0 < b; r0 += step) {
+                int r1 = Math.min(b, r0 + step);
+                long bytes = (long) (r1 - r0) * n * Double.BYTES;
+                MemorySegment x = stage.asSlice(0, bytes);
+                MemorySegment y = stage.asSlice(half, bytes);
+                pack(x, signals, r0, r1, n);
+                int st = (int) VwGpuNative.VW_SWT_DENOISE_BATCH.invokeExact(ctx, x, (long) (r1 - r0), (long) n, levels, th,
+                    h.length, tg, g.length, thr, hr.length, tgr, gr.length, boundary(mode), threshold,
+                    sqrt2lnN, soft ? 1 : 0, y, MemorySegment.NULL);
+                check(st, -1);
+                unpack(y, out, r0, r1, n);
+            }
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -266,21 +352,27 @@ public final class GpuModwtBackend implements AutoCloseable {
      * 377-395) for B coefficient blocks [B][J+1][N]: median(|d_1|) / 0.6745 * sqrt(2 ln N), the median from the
      * exact order statistics the reference's sort yields.
      */
-    public double[] universalThresholds(double[] coeffs, int b, int n, int levels) {
+    public double[] universalThresholds(double[][] coeffs, int n, int levels) {
+        int b = coeffs.length;
+        int perRow = Math.multiplyExact(levels + 1, n);
         double[] out = new double[b];
         if (b == 0) {
             return out;
         }
-        long cBytes = (long) coeffs.length * Double.BYTES;
-        MemorySegment stage = acquire(cBytes + (long) b * Double.BYTES);
+        int step = rowsPerCall(perRow, 1, b);
+        long cCap = (long) step * perRow * Double.BYTES;
+        MemorySegment stage = acquire(cCap + (long) step * Double.BYTES);
         try {
-            MemorySegment c = stage.asSlice(0, cBytes);
-            MemorySegment thr = stage.asSlice(cBytes, (long) b * Double.BYTES);
-            MemorySegment.copy(coeffs, 0, c, JAVA_DOUBLE, 0, coeffs.length);
-            int st = (int) VwGpuNative.VW_SWT_UNIVERSAL_THRESHOLD_BATCH.invokeExact(ctx, c, (long) b, (long) n, levels,
-                Math.sqrt(2 * Math.log(n)), thr);
-            check(st, -1);
-            MemorySegment.copy(thr, JAVA_DOUBLE, 0, out, 0, b);
+            for (int r0 = 0; r0 < b; r0 += step) {
+                int r1 = Math.min(b, r0 + step);
+                MemorySegment c = stage.asSlice(0, (long) (r1 - r0) * perRow * Double.BYTES);
+                MemorySegment thr = stage.asSlice(cCap, (long) (r1 - r0) * Double.BYTES);
+                pack(c, coeffs, r0, r1, perRow);
+                int st = (int) VwGpuNative.VW_SWT_UNIVERSAL_THRESHOLD_BATCH.invokeExact(ctx, c, (long) (r1 - r0), (long) n, levels,
+                    Math.sqrt(2 * Math.log(n)), thr);
+                check(st, -1);
+                MemorySegment.copy(thr, JAVA_DOUBLE, 0, out, r0, r1 - r0);
+            }
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -304,23 +396,32 @@ public final class GpuModwtBackend implements AutoCloseable {
         if (b == 0) {
             return out;
         }
-        long xBytes = (long) b * n * Double.BYTES;
-        MemorySegment stage = acquire(2 * xBytes);
+        int step = rowsPerCall(n, n, b);
+        double[] h = w.lowPassDecomposition();
+        double[] g = w.highPassDecomposition();
+        double[] hr = w.lowPassReconstruction();
+        double[] gr = w.highPassReconstruction();
+        int flags = levels == 0 ? VwGpuNative.FLAG_SINGLE_LEVEL : 0;
+        long half = (long) step * n * Double.BYTES;
+        MemorySegment stage = acquire(2 * half);
         try (Arena a = Arena.ofConfined()) {
-            MemorySegment x = stage.asSlice(0, xBytes);
-            MemorySegment y = stage.asSlice(xBytes, xBytes);
-            pack(x, signals, n);
-            double[] h = w.lowPassDecomposition();
-            double[] g = w.highPassDecomposition();
-            double[] hr = w.lowPassReconstruction();
-            double[] gr = w.highPassReconstruction();
-            int flags = levels == 0 ? VwGpuNative.FLAG_SINGLE_LEVEL : 0;
-            // Math.log stays on the JVM so that the thresholds match the CPU path bit for bit
-            int st = (int) VwGpuNative.VW_WAVELET_DENOISE_BATCH.invokeExact(ctx, x, (long) b, (long) n, Math.max(levels, 1),
-                taps(a, h), h.length, taps(a, g), g.length, taps(a, hr), hr.length, taps(a, gr), gr.length,
-                boundary(mode), flags, method, soft ? 1 : 0, fixedThreshold, Math.log(n), y, MemorySegment.NULL);
-            check(st, -1);
-            unpack(y, out, n);
+            MemorySegment th = taps(a, h);
+            MemorySegment tg = taps(a, g);
+            MemorySegment thr = taps(a, hr);
+            MemorySegment tgr = taps(a, gr);
+            for (int r0 = 0; r0 < b; r0 += step) {
+                int r1 = Math.min(b, r0 + step);
+                long bytes = (long) (r1 - r0) * n * Double.BYTES;
+                MemorySegment x = stage.asSlice(0, bytes);
+                MemorySegment y = stage.asSlice(half, bytes);
+                pack(x, signals, r0, r1, n);
+                // Math.log stays on the JVM so that the thresholds match the CPU path bit for bit
+                int st = (int) VwGpuNative.VW_WAVELET_DENOISE_BATCH.invokeExact(ctx, x, (long) (r1 - r0), (long) n,
+                    Math.max(levels, 1), th, h.length, tg, g.length, thr, hr.length, tgr, gr.length,
+                    boundary(mode), flags, method, soft ? 1 : 0, fixedThreshold, Math.log(n), y, MemorySegment.NULL);
+                check(st, -1);
+                unpack(y, out, r0, r1, n);
+            }
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -388,12 +489,13 @@ public final class GpuModwtBackend implements AutoCloseable {
         if (b == 0) {
             return out;
         }
-        long xBytes = (long) b * n * Double.BYTES;
+        // (one block per stream and call: the state advances once per call, so this batch is not cut into chunks)
+        long xBytes = Math.multiplyExact((long) b * n, (long) Double.BYTES);
         MemorySegment stage = acquire(2 * xBytes);
         try (Arena a = Arena.ofConfined()) {
             MemorySegment x = stage.asSlice(0, xBytes);
             MemorySegment y = stage.asSlice(xBytes, xBytes);
-            pack(x, blocks, n);
+            pack(x, blocks, 0, b, n);
             double[] h = w.lowPassDecomposition();
             double[] g = w.highPassDecomposition();
             double[] hr = w.lowPassReconstruction();
@@ -404,7 +506,7 @@ public final class GpuModwtBackend implements AutoCloseable {
                 h.length, taps(a, g), g.length, taps(a, hr), hr.length, taps(a, gr), gr.length, boundary(mode), 0, method,
                 soft ? 1 : 0, thresholdMultiplier, noiseEstimation, logN, Math.sqrt(2.0 * logN), y, MemorySegment.NULL);
             check(st, -1);
-            unpack(y, out, n);
+            unpack(y, out, 0, b, n);
             return out;
         } catch (RuntimeException | Error e) {
             throw e;
@@ -446,18 +548,29 @@ public final class GpuModwtBackend implements AutoCloseable {
         }
     }
 
+    /**
+     * Idempotent.  The first call wins; the instance leaves the shared map (so {@link #shared} builds a new one), pooled
+     * staging buffers are freed, and the native context is destroyed now or, when calls are still in flight on other
+     * threads, when the last of their staging segments comes back.
+     */
     @Override
     public void close() {
-        closed = true;
+        if (!closed.compareAndSet(false, true)) {
+            return;
+        }
+        SHARED.remove(device, this);
+        boolean destroyNow;
         synchronized (freeStaging) {
             while (!freeStaging.isEmpty()) {
                 VwGpuNative.hostFree(ctx, freeStaging.removeFirst());
             }
+            destroyNow = outstanding == 0 && !destroyed;
+            if (destroyNow) {
+                destroyed = true;
+            }
         }
-        try {
-            int ignored = (int) VwGpuNative.VW_DESTROY.invokeExact(ctx);
-        } catch (Throwable t) {
-            throw new IllegalStateException(t);
+        if (destroyNow) {
+            destroyContext();
         }
     }
 }

@@ -59,26 +59,27 @@ public class MODWTTransform {
                     .build());
         }
         ValidationUtils.validateFiniteValues(signal, "signal");
-        double[] c = GpuModwtBackend.shared().forward(new double[][] {signal}, wavelet, boundaryMode, 1, true, false);
-        return resultAt(c, 0, signal.length);
+        double[][] c = GpuModwtBackend.shared().forward(new double[][] {signal}, wavelet, boundaryMode, 1, true, false);
+        return resultOf(c[0], signal.length);
     }
 
-    /** Row b of a single-level coefficient block [B][2][N] (detail, approximation) as a MODWTResult. */
-    private static MODWTResult resultAt(double[] block, int b, int n) {
+    /** One signal's single-level coefficient block [2][N] (detail, approximation) as a MODWTResult. */
+    private static MODWTResult resultOf(double[] block, int n) {
         double[] detail = new double[n];
         double[] approx = new double[n];
-        System.arraycopy(block, 2 * b * n, detail, 0, n);
-        System.arraycopy(block, (2 * b + 1) * n, approx, 0, n);
+        System.arraycopy(block, 0, detail, 0, n);
+        System.arraycopy(block, n, approx, 0, n);
         return MODWTResult.create(approx, detail);
     }
 
-    private static double[] blockOf(MODWTResult[] results, int n) {
-        double[] block = new double[Math.multiplyExact(2 * results.length, n)];
+    /** One block [2][N] (detail, approximation) per result. */
+    private static double[][] blocksOf(MODWTResult[] results, int n) {
+        double[][] blocks = new double[results.length][Math.multiplyExact(2, n)];
         for (int b = 0; b < results.length; b++) {
-            System.arraycopy(results[b].detailCoeffs(), 0, block, 2 * b * n, n);
-            System.arraycopy(results[b].approximationCoeffs(), 0, block, (2 * b + 1) * n, n);
+            System.arraycopy(results[b].detailCoeffs(), 0, blocks[b], 0, n);
+            System.arraycopy(results[b].approximationCoeffs(), 0, blocks[b], n, n);
         }
-        return block;
+        return blocks;
     }
 
     /** :193-291: null -> NullPointerException; non-finite coefficients -> VAL_NON_FINITE_VALUES. */
@@ -93,8 +94,8 @@ public class MODWTTransform {
                     .build());
         }
         int n = modwtResult.getSignalLength();
-        double[] block = blockOf(new MODWTResult[] {modwtResult}, n);
-        return GpuModwtBackend.shared().inverse(block, 1, n, wavelet, boundaryMode, 1, true, false, -1)[0];
+        double[][] blocks = blocksOf(new MODWTResult[] {modwtResult}, n);
+        return GpuModwtBackend.shared().inverse(blocks, n, wavelet, boundaryMode, 1, true, false, -1)[0];
     }
 
     public Wavelet getWavelet() {
@@ -165,9 +166,9 @@ public class MODWTTransform {
         }
         MODWTResult[] results = new MODWTResult[signals.length];
         if (sameLengths && signals.length >= 4 && n >= 64) {
-            double[] c = GpuModwtBackend.shared().forward(signals, wavelet, boundaryMode, 1, true, false);
+            double[][] c = GpuModwtBackend.shared().forward(signals, wavelet, boundaryMode, 1, true, false);
             for (int b = 0; b < signals.length; b++) {
-                results[b] = resultAt(c, b, n);
+                results[b] = resultOf(c[b], n);
             }
             return results;
         }
@@ -192,8 +193,7 @@ public class MODWTTransform {
             sameLengths = results[i].getSignalLength() == n;
         }
         if (sameLengths && results.length >= 4 && n >= 64) {
-            return GpuModwtBackend.shared().inverse(blockOf(results, n), results.length, n, wavelet, boundaryMode, 1, true,
-                true, -1);
+            return GpuModwtBackend.shared().inverse(blocksOf(results, n), n, wavelet, boundaryMode, 1, true, true, -1);
         }
         double[][] reconstructed = new double[results.length][];
         for (int i = 0; i < results.length; i++) {

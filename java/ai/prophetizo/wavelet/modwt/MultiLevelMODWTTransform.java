@@ -71,33 +71,34 @@ public class MultiLevelMODWTTransform {
         }
     }
 
-    private static double[] band(double[] block, int row, int bandsPerRow, int k, int n) {
+    /** Band k of one signal's block [J+1][N] (d_1..d_J, a_J). */
+    private static double[] band(double[] block, int k, int n) {
         double[] out = new double[n];
-        System.arraycopy(block, (row * bandsPerRow + k) * n, out, 0, n);
+        System.arraycopy(block, k * n, out, 0, n);
         return out;
     }
 
-    private static MultiLevelMODWTResult immutableAt(double[] block, int row, int levels, int n) {
+    private static MultiLevelMODWTResult immutableOf(double[] block, int levels, int n) {
         MultiLevelMODWTResultImpl r = new MultiLevelMODWTResultImpl(n, levels);
         for (int level = 1; level <= levels; level++) {
-            r.setDetailCoeffsAtLevel(level, band(block, row, levels + 1, level - 1, n));
+            r.setDetailCoeffsAtLevel(level, band(block, level - 1, n));
         }
-        r.setApproximationCoeffs(band(block, row, levels + 1, levels, n));
+        r.setApproximationCoeffs(band(block, levels, n));
         return r;
     }
 
-    private static MutableMultiLevelMODWTResult mutableAt(double[] block, int row, int levels, int n) {
+    private static MutableMultiLevelMODWTResult mutableOf(double[] block, int levels, int n) {
         MutableMultiLevelMODWTResultImpl r = new MutableMultiLevelMODWTResultImpl(n, levels);
         for (int level = 1; level <= levels; level++) {
-            r.setDetailCoeffsAtLevelDirect(level, band(block, row, levels + 1, level - 1, n));
+            r.setDetailCoeffsAtLevelDirect(level, band(block, level - 1, n));
         }
-        r.setApproximationCoeffsDirect(band(block, row, levels + 1, levels, n));
+        r.setApproximationCoeffsDirect(band(block, levels, n));
         return r;
     }
 
-    /** The [B][J+1][N] block (d_1..d_J, a_J per row) of results that share levels and length. */
-    private static double[] blockOf(MultiLevelMODWTResult[] results, int levels, int n) {
-        double[] block = new double[Math.multiplyExact(Math.multiplyExact(results.length, levels + 1), n)];
+    /** One block [J+1][N] (d_1..d_J, a_J) per result; the results share levels and length. */
+    private static double[][] blocksOf(MultiLevelMODWTResult[] results, int levels, int n) {
+        double[][] blocks = new double[results.length][Math.multiplyExact(levels + 1, n)];
         for (int b = 0; b < results.length; b++) {
             MultiLevelMODWTResult r = Objects.requireNonNull(results[b], "result cannot be null");
             if (r.getLevels() != levels || r.getSignalLength() != n) {
@@ -105,14 +106,14 @@ public class MultiLevelMODWTTransform {
                     "Results of one batch must share the level count and the signal length");
             }
             for (int level = 1; level <= levels; level++) {
-                System.arraycopy(r.getDetailCoeffsAtLevel(level), 0, block, (b * (levels + 1) + level - 1) * n, n);
+                System.arraycopy(r.getDetailCoeffsAtLevel(level), 0, blocks[b], (level - 1) * n, n);
             }
-            System.arraycopy(r.getApproximationCoeffs(), 0, block, (b * (levels + 1) + levels) * n, n);
+            System.arraycopy(r.getApproximationCoeffs(), 0, blocks[b], levels * n, n);
         }
-        return block;
+        return blocks;
     }
 
-    private double[] decomposeBlock(double[][] signals, int levels) {
+    private double[][] decomposeBlocks(double[][] signals, int levels) {
         return GpuModwtBackend.shared().forward(signals, wavelet, boundaryMode, levels, false, false);
     }
 
@@ -124,7 +125,7 @@ public class MultiLevelMODWTTransform {
     /** :214-268 */
     public MultiLevelMODWTResult decompose(double[] signal, int levels) {
         validate(signal, levels, "Multi-level MODWT");
-        return immutableAt(decomposeBlock(new double[][] {signal}, levels), 0, levels, signal.length);
+        return immutableOf(decomposeBlocks(new double[][] {signal}, levels)[0], levels, signal.length);
     }
 
     /** :281-284 */
@@ -135,7 +136,7 @@ public class MultiLevelMODWTTransform {
     /** :299-353 */
     public MutableMultiLevelMODWTResult decomposeMutable(double[] signal, int levels) {
         validate(signal, levels, "Multi-level MODWT (mutable)");
-        return mutableAt(decomposeBlock(new double[][] {signal}, levels), 0, levels, signal.length);
+        return mutableOf(decomposeBlocks(new double[][] {signal}, levels)[0], levels, signal.length);
     }
 
     /**
@@ -151,9 +152,9 @@ public class MultiLevelMODWTTransform {
         if (signals.length == 0) {
             return out;
         }
-        double[] block = decomposeBlock(signals, levels);
+        double[][] blocks = decomposeBlocks(signals, levels);
         for (int b = 0; b < signals.length; b++) {
-            out[b] = immutableAt(block, b, levels, signals[0].length);
+            out[b] = immutableOf(blocks[b], levels, signals[0].length);
         }
         return out;
     }
@@ -168,9 +169,9 @@ public class MultiLevelMODWTTransform {
         if (signals.length == 0) {
             return out;
         }
-        double[] block = decomposeBlock(signals, levels);
+        double[][] blocks = decomposeBlocks(signals, levels);
         for (int b = 0; b < signals.length; b++) {
-            out[b] = mutableAt(block, b, levels, signals[0].length);
+            out[b] = mutableOf(blocks[b], levels, signals[0].length);
         }
         return out;
     }
@@ -178,8 +179,8 @@ public class MultiLevelMODWTTransform {
     private double[] reconstructMasked(MultiLevelMODWTResult result, int bandMask) {
         int levels = result.getLevels();
         int n = result.getSignalLength();
-        double[] block = blockOf(new MultiLevelMODWTResult[] {result}, levels, n);
-        return GpuModwtBackend.shared().inverse(block, 1, n, wavelet, boundaryMode, levels, false, false, bandMask)[0];
+        double[][] blocks = blocksOf(new MultiLevelMODWTResult[] {result}, levels, n);
+        return GpuModwtBackend.shared().inverse(blocks, n, wavelet, boundaryMode, levels, false, false, bandMask)[0];
     }
 
     /** :362-375 */
@@ -196,8 +197,7 @@ public class MultiLevelMODWTTransform {
         }
         int levels = Objects.requireNonNull(results[0], "result cannot be null").getLevels();
         int n = results[0].getSignalLength();
-        return GpuModwtBackend.shared().inverse(blockOf(results, levels, n), results.length, n, wavelet, boundaryMode, levels,
-            false, false, -1);
+        return GpuModwtBackend.shared().inverse(blocksOf(results, levels, n), n, wavelet, boundaryMode, levels, false, false, -1);
     }
 
     /**

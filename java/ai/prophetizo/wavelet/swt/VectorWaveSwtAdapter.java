@@ -72,7 +72,7 @@ public class VectorWaveSwtAdapter {
         int n = result.getSignalLength();
         double[] block = new double[(levels + 1) * n];
         System.arraycopy(result.getMutableDetailCoeffs(1), 0, block, 0, n);  // only d_1 is read
-        double threshold = GpuModwtBackend.shared().universalThresholds(block, 1, n, levels)[0];
+        double threshold = GpuModwtBackend.shared().universalThresholds(new double[][] {block}, n, levels)[0];
         for (int level = 1; level <= levels; level++) {
             applyThreshold(result, level, threshold, soft);
         }
@@ -130,7 +130,7 @@ public class VectorWaveSwtAdapter {
             System.arraycopy(result.getMutableDetailCoeffs(level), 0, block, (level - 1) * n, n);
         }
         System.arraycopy(result.getMutableApproximationCoeffs(), 0, block, levels * n, n);
-        return GpuModwtBackend.shared().inverse(block, 1, n, wavelet, boundaryMode, levels, false, false, mask)[0];
+        return GpuModwtBackend.shared().inverse(new double[][] {block}, n, wavelet, boundaryMode, levels, false, false, mask)[0];
     }
 
     public Wavelet getWavelet() {

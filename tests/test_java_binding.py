@@ -119,9 +119,10 @@ def test_java_sources_use_only_declared_handles_and_constants():
                         seen_handles.add(name)
                 else:
                     assert name in declared_methods, "%s calls VwGpuNative.%s(), which is not declared" % (f, name)
-    # the three drop-in classes and the backend reach the hot path
+    # the drop-in classes and the backend reach the hot path
     for needed in ("VW_MODWT_FORWARD_BATCH", "VW_MODWT_INVERSE_BATCH", "VW_MODWT_INVERSE_BANDS_BATCH", "VW_SWT_DENOISE_BATCH",
-                   "VW_SWT_UNIVERSAL_THRESHOLD_BATCH", "VW_MAX_LEVELS", "VW_DESTROY"):
+                   "VW_SWT_UNIVERSAL_THRESHOLD_BATCH", "VW_MAX_LEVELS", "VW_DESTROY", "VW_WAVELET_DENOISE_BATCH",
+                   "VW_STREAMING_DENOISE_BATCH", "VW_STREAM_STATE_CREATE", "VW_STREAM_STATE_DESTROY", "VW_BATCH_MODWT_SOA"):
         assert needed in seen_handles, needed + " is bound but never called from the Java host side"
 
 
@@ -184,8 +185,10 @@ def test_generated_block_is_current():
 
 
 def test_facade_classes_keep_the_reference_signatures():
-    """The public surface of the three drop-in classes, as the reference declares it (signatures listed from
-    modwt/MODWTTransform.java:83-504, modwt/MultiLevelMODWTTransform.java:186-785, swt/VectorWaveSwtAdapter.java:122-423)."""
+    """The public surface of the drop-in classes, as the reference declares it (signatures listed from
+    modwt/MODWTTransform.java:83-504, modwt/MultiLevelMODWTTransform.java:186-785, swt/VectorWaveSwtAdapter.java:122-423,
+    denoising/WaveletDenoiser.java:79-634, modwt/streaming/MODWTStreamingDenoiser.java:35-506,
+    modwt/BatchSIMDMODWT.java:64-328, modwt/ParallelMultiLevelMODWT.java:37-60)."""
     want = {
         "modwt/MODWTTransform.java": [
             "public MODWTTransform(Wavelet wavelet, BoundaryMode boundaryMode)",
@@ -228,8 +231,127 @@ def test_facade_classes_keep_the_reference_signatures():
             "public void cleanup()",
             "public Map<String, Object> getCacheStatistics()",
         ],
+        "denoising/WaveletDenoiser.java": [
+            "public class WaveletDenoiser",
+            "public WaveletDenoiser(Wavelet wavelet, BoundaryMode boundaryMode)",
+            "public static WaveletDenoiser forFinancialData()",
+            "public double[] denoise(double[] signal, ThresholdMethod method)",
+            "public double[] denoise(double[] signal, ThresholdMethod method, ThresholdType type)",
+            "public double[] denoiseMultiLevel(double[] signal, int levels, ThresholdMethod method, ThresholdType type)",
+            "public double[] denoiseFixed(double[] signal, double threshold, ThresholdType type)",
+            "public enum ThresholdMethod",
+            "public enum ThresholdType",
+        ],
+        "modwt/streaming/MODWTStreamingDenoiser.java": [
+            "public class MODWTStreamingDenoiser implements Flow.Publisher<double[]>, AutoCloseable",
+            "public enum NoiseEstimation",
+            "private MODWTStreamingDenoiser(Builder builder)",
+            "public double[] denoise(double[] samples)",
+            "public double getEstimatedNoiseLevel()",
+            "public long getSamplesProcessed()",
+            "public void subscribe(Flow.Subscriber<? super double[]> subscriber)",
+            "public void close()",
+            "public boolean isClosed()",
+            "public static class Builder",
+            "public Builder wavelet(Wavelet wavelet)",
+            "public Builder boundaryMode(BoundaryMode boundaryMode)",
+            "public Builder bufferSize(int bufferSize)",
+            "public Builder thresholdType(ThresholdType thresholdType)",
+            "public Builder thresholdMethod(ThresholdMethod thresholdMethod)",
+            "public Builder thresholdMultiplier(double thresholdMultiplier)",
+            "public Builder noiseEstimation(NoiseEstimation noiseEstimation)",
+            "public Builder noiseWindowSize(int noiseWindowSize)",
+            "public MODWTStreamingDenoiser build()",
+        ],
+        "modwt/BatchSIMDMODWT.java": [
+            "public final class BatchSIMDMODWT",
+            "public static void batchMODWTSoA(double[] soaSignals, double[] soaApprox, double[] soaDetail, "
+            "DiscreteWavelet wavelet, int batchSize, int signalLength)",
+            "public static void convertToSoA(double[][] signals, double[] soaOutput)",
+            "public static void convertFromSoA(double[] soaData, double[][] output)",
+            "public static void batchMODWTWithCleanup(double[] soaSignals, double[] soaApprox, double[] soaDetail, "
+            "DiscreteWavelet wavelet, int batchSize, int signalLength)",
+        ],
+        "modwt/ParallelMultiLevelMODWT.java": [
+            "public class ParallelMultiLevelMODWT",
+            "public ParallelMultiLevelMODWT()",
+            "public ParallelMultiLevelMODWT(Executor executor)",
+            "public MultiLevelMODWTResult decompose(double[] signal, Wavelet wavelet, BoundaryMode mode, int levels)",
+        ],
     }
+    # enum constants in the reference's order: their ordinals cross the C ABI as VW_THRESHOLD_* / VW_NOISE_*
+    den = " ".join(re.sub(r"/\*.*?\*/", " ", open(os.path.join(JAVA_DIR, "denoising/WaveletDenoiser.java")).read(), flags=re.S).split())
+    assert re.search(r"enum ThresholdMethod \{ UNIVERSAL, SURE, MINIMAX, BAYES, FIXED \}", den), "ThresholdMethod order"
+    assert re.search(r"enum ThresholdType \{ SOFT, HARD \}", den), "ThresholdType order"
+    stream = " ".join(re.sub(r"/\*.*?\*/", " ", open(os.path.join(JAVA_DIR, "modwt/streaming/MODWTStreamingDenoiser.java")).read(),
+                             flags=re.S).split())
+    assert re.search(r"enum NoiseEstimation \{ MAD, STD, FIXED \}", stream), "NoiseEstimation order"
+    hdr = _strip_c(open(HEADER).read())
+    enums = dict((k, int(v)) for k, v in re.findall(r"\b(VW_[A-Z_]+)\s*=\s*(\d+)", hdr))
+    for i, name in enumerate(["UNIVERSAL", "SURE", "MINIMAX", "BAYES", "FIXED"]):
+        assert enums["VW_THRESHOLD_" + name] == i
+    for i, name in enumerate(["MAD", "STD", "FIXED"]):
+        assert enums["VW_NOISE_" + name] == i
     for rel, sigs in want.items():
         src = " ".join(open(os.path.join(JAVA_DIR, rel)).read().split())
         for s in sigs:
             assert s in src, "%s lacks `%s`" % (rel, s)
+
+
+def _split_top_level(argtext):
+    depth, cur, out = 0, "", []
+    for ch in argtext:
+        if ch in "([{<":
+            depth += 1
+        elif ch in ")]}>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _call_args(src, start):
+    """Text between the parenthesis at src[start - 1] and its partner."""
+    i, depth = start, 1
+    while depth:
+        ch = src[i]
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        i += 1
+    return src[start:i - 1]
+
+
+def test_facades_call_backend_methods_that_exist_with_that_many_arguments():
+    """No JDK here, so the cheapest compile error is checked by hand: every call of a GpuModwtBackend method from the
+    drop-in classes names a public method of the backend and passes as many arguments as one of its overloads takes."""
+    backend_src = open(os.path.join(JAVA_DIR, "gpu", "GpuModwtBackend.java")).read()
+    backend_src = re.sub(r"/\*.*?\*/", " ", backend_src, flags=re.S)
+    backend_src = re.sub(r"//[^\n]*", " ", backend_src)
+    declared = {}
+    for m in re.finditer(r"public\s+(?:static\s+)?[\w<>\[\], ]+?\s+(\w+)\s*\(", backend_src):
+        args = _call_args(backend_src, m.end())
+        declared.setdefault(m.group(1), set()).add(len(_split_top_level(args)))
+    assert {"forward", "inverse", "denoise", "waveletDenoise", "streamingDenoise", "batchMODWTSoA"} <= set(declared)
+    calls = 0
+    for dirpath, _, files in os.walk(JAVA_DIR):
+        for f in files:
+            if not f.endswith(".java") or f in ("GpuModwtBackend.java", "VwGpuNative.java"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+            src = re.sub(r"//[^\n]*", " ", src)
+            for m in re.finditer(r"(?:GpuModwtBackend\s*\.\s*shared\(\)|\bbackend)\s*\.\s*(\w+)\s*\(", src):
+                name = m.group(1)
+                nargs = len(_split_top_level(_call_args(src, m.end())))
+                assert name in declared, "%s calls GpuModwtBackend.%s, which the backend does not declare" % (f, name)
+                assert nargs in declared[name], "%s: %s called with %d arguments, declared with %s" % (
+                    f, name, nargs, sorted(declared[name]))
+                calls += 1
+    assert calls >= 20
