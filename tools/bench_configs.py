@@ -50,9 +50,12 @@ def main():
         ("C1 db4 32x1000 single level", "db4", 32, 1000, 1, 0, N.VW_FLAG_SINGLE_LEVEL),
         ("C2 haar 4096x65536 J=6", "haar", 4096, 65536, 6, 0, 0),
         ("C2 db4 4096x65536 J=6", "db4", 4096, 65536, 6, 0, 0),
+        ("C2 db4 4096x65536 J=6 ZERO_PADDING", "db4", 4096, 65536, 6, 1, 0),
+        ("C2 db4 4096x65536 J=6 SYMMETRIC", "db4", 4096, 65536, 6, 2, 0),
         ("C3 sym8 64x777777 J=8 PERIODIC", "sym8", 64, 777777, 8, 0, 0),
         ("C3 sym8 64x777777 J=8 ZERO_PADDING", "sym8", 64, 777777, 8, 1, 0),
         ("C3 coif3 64x777777 J=8 PERIODIC", "coif3", 64, 777777, 8, 0, 0),
+        ("C3 coif3 64x777777 J=8 ZERO_PADDING", "coif3", 64, 777777, 8, 1, 0),
         ("C3 db10 64x777777 J=8 PERIODIC", "db10", 64, 777777, 8, 0, 0),
         ("C3 db10 64x777777 J=8 ZERO_PADDING", "db10", 64, 777777, 8, 1, 0),
         ("C4 db4 65536x16384 J=6", "db4", 65536, 16384, 6, 0, 0),

@@ -58,6 +58,7 @@ struct PlanOptions {
                                          // (measured 6 % faster than pairs, aligned or not), 1 / 2 pairs, -1 by alignment
     int no_band_regs = 0;                // 1: the row-resident denoise keeps every detail band in LDS
     int no_vec2 = 0;                     // 1: the inverse tile kernels access global memory one sample at a time
+    int no_sym_tiles = 0;                // 1: SYMMETRIC always through the generic one-level kernels
 #ifdef VW_TUNING
     char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
 #endif
@@ -222,6 +223,8 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_vec2 = value != 0;
     } else if (strcmp(name, "no_band_regs") == 0) {
         o.no_band_regs = value != 0;
+    } else if (strcmp(name, "no_sym_tiles") == 0) {
+        o.no_sym_tiles = value != 0;
     } else {
         return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
     }
@@ -233,7 +236,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "inv_wave_nt", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs"};
+                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "inv_wave_nt", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs", "no_sym_tiles"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -639,19 +642,27 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
     const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
     double* aslot = coeffs + static_cast<int64_t>(levels) * n;  // row 0 of the a_J band
 
-    // truncation (multi-level API only) and boundary decide fused vs generic
-    bool generic_all = (boundary == VW_BOUNDARY_SYMMETRIC);
+    // truncation (multi-level API only) and boundary decide fused vs generic.  SYMMETRIC rides the tile-streaming
+    // kernel only (one halo chunk, mirrored level by level in the first tile of a row): rows of at least one chunk,
+    // level groups whose context fits one chunk
+    const bool sym = (boundary == VW_BOUNDARY_SYMMETRIC);
+    bool generic_all = sym && (n < kChunk || ctx->opt.no_sym_tiles);
     if (!single) {
         for (int j = 1; j <= levels; ++j) {
             const int64_t s = static_cast<int64_t>(1) << (j - 1);
             if (truncated_taps(lh, s, n) != lh || truncated_taps(lg, s, n) != lg) generic_all = true;
         }
     }
+    auto pick = [&](int64_t hneed, TileCfg* out) {
+        if (sym && hneed + 2 > kChunk) return false;
+        if (!pick_cfg(ctx, n, hneed, fwd_cfgs(), out)) return false;
+        return !sym || out->hpt == 1;
+    };
 
     // ---- plan ----------------------------------------------------------------
     StepList steps;
     // a context beyond one chunk: all levels in one pass of the long-context streaming kernel if it fits
-    if (!generic_all && fwd_halo(1, levels, lh, lg, nullptr) + 2 > kChunk) {
+    if (!generic_all && !sym && fwd_halo(1, levels, lh, lg, nullptr) + 2 > kChunk) {
         Step st;
         st.lev0 = 1;
         st.lev1 = levels;
@@ -671,14 +682,14 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
             if (!generic_all) {
                 int hi = j;
                 TileCfg cfg;
-                if (pick_cfg(ctx, n, fwd_halo(j, j, lh, lg, nullptr), fwd_cfgs(), &cfg)) {
+                if (pick(fwd_halo(j, j, lh, lg, nullptr), &cfg)) {
                     st.fused = true;
                     st.cfg = cfg;
                     while (hi + 1 <= levels) {
                         TileCfg c2;
                         const int64_t hneed = fwd_halo(j, hi + 1, lh, lg, nullptr);
                         if (hneed + 2 > static_cast<int64_t>(kHaloMaxChunks) * kChunk) break;
-                        if (!pick_cfg(ctx, n, hneed, fwd_cfgs(), &c2)) break;
+                        if (!pick(hneed, &c2)) break;
                         st.cfg = c2;
                         ++hi;
                     }
@@ -793,7 +804,8 @@ static int forward_dev(vw_ctx* ctx, const double* x, int64_t b, int64_t n, int l
                               aligned16(coeffs) && aligned16(vout);
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
+            // (VW_FLAG_FMA permits fused rounding, it does not demand it: SYMMETRIC keeps the reference's arithmetic)
+            hipError_t e = launch_fwd(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0 && !sym, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "forward kernel launch: %s", hipGetErrorString(e));
         } else {
             if (first && first_bad_cell != nullptr) {
@@ -925,14 +937,17 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
     const int64_t rowc = static_cast<int64_t>(levels + 1) * n;
     const double* aslot = coeffs + static_cast<int64_t>(levels) * n;
 
-    bool generic_all = (boundary == VW_BOUNDARY_SYMMETRIC);
+    // SYMMETRIC: the left-looking tile kernel (k_inv_sym) for the multi-level form and for MODWTTransform.inverse;
+    // inverseBatchOptimized's flavour (reflects t + l) stays with the generic kernel
+    const bool sym = (boundary == VW_BOUNDARY_SYMMETRIC);
+    bool generic_all = sym && (n < kChunk || ctx->opt.no_sym_tiles || (single && (flags & VW_FLAG_SYMMETRIC_BATCH_VARIANT)));
     if (!single) {
         for (int j = 1; j <= levels; ++j) {
             const int64_t s = static_cast<int64_t>(1) << (j - 1);
             if (truncated_taps(lhr, s, n) != lhr || truncated_taps(lgr, s, n) != lgr) generic_all = true;
         }
     }
-    if (generic_all && thr_mode != 0) return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
+    if ((generic_all || sym) && thr_mode != 0) return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
 
     StepList steps;
     {
@@ -945,6 +960,19 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             st.cfg = TileCfg{0, 0, kThreads};
             // a context beyond one chunk: as many of the remaining levels as fit one pass of the
             // long-context streaming kernel
+            if (!generic_all && sym) {
+                // as many of the remaining levels as keep their joint left context inside one halo chunk
+                if (inv_sym_supported(lhr, lgr, j, j, n)) {
+                    int lo = j;
+                    while (lo - 1 >= 1 && inv_sym_supported(lhr, lgr, lo - 1, j, n)) --lo;
+                    st.lev0 = lo;
+                    st.fused = true;
+                    st.cfg = TileCfg{n >= 4 * kChunk ? 4 : 1, 1, kThreads};
+                }
+                steps.push_back(st);
+                j = st.lev0 - 1;
+                continue;
+            }
             if (!generic_all && inv_halo(1, j, lhr) + 2 > kChunk) {
                 for (int lo = 1; lo <= j && st.sdry == 0; ++lo) {
                     st.sdry = plan_sdry(ctx, lo, j, lhr, true, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
@@ -1039,6 +1067,47 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             plan_note(ctx->plan_inv, "k_inv_sdry", st.lev0, st.lev1);
             hipError_t e = launch_inv_sdry(a, st.sdry, boundary, ctx->opt.inv_vm >= 0 ? (ctx->opt.inv_vm == 1 && !vec2 ? 2 : ctx->opt.inv_vm) : (vec2 ? 1 : 2), (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(e));
+        } else if (st.fused && sym) {
+            InvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.rin = rin;
+            a.rin_stride = rin_stride;
+            a.win = coeffs;
+            a.w_row_stride = rowc;
+            a.w_band_stride = band;
+            a.rout = rout;
+            a.rout_stride = rstride;
+            a.n = n;
+            a.n_store = n;
+            a.nrows = b;
+            const int T = st.cfg.tile();
+            a.ntiles = static_cast<int32_t>((n + T - 1) / T);
+            a.lev0 = st.lev0;
+            a.lev1 = st.lev1;
+            a.lh = lhr;
+            a.lg = lgr;
+            // first halo position from which R_j is valid: everything that was loaded for R_{lev1}, then the joint left
+            // context of the levels undone so far
+            const int lmax = lhr > lgr ? lhr : lgr;
+            a.pend[st.lev1] = 0;
+            for (int j = st.lev1; j > st.lev0; --j) {
+                int64_t v = a.pend[j] + static_cast<int64_t>(lmax - 1) * (static_cast<int64_t>(1) << (j - 1));
+                v = (v + 1) & ~static_cast<int64_t>(1);
+                a.pend[j - 1] = static_cast<int32_t>(v < kChunk ? v : kChunk);
+            }
+            a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
+            a.thr_mode = 0;
+            a.first_bad = first_bad_cell;
+            a.check_rin = first ? 1 : 0;
+            a.taps = taps;
+            a.nt_store = streaming_stores(ctx->opt, b, n, levels);
+            const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout) &&
+                              !ctx->opt.no_vec2;
+            const int64_t nblocks = b * a.ntiles;
+            if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+            plan_note(ctx->plan_inv, "k_inv_sym", st.lev0, st.lev1);
+            hipError_t er = launch_inv_sym(a, st.cfg.ppt, vec2, single, nblocks, stream);
+            if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));
         } else if (st.fused) {
             InvArgs a;
             memset(&a, 0, sizeof(a));

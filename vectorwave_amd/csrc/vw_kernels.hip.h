@@ -79,6 +79,7 @@ struct InvArgs {
     int32_t ntiles;
     int32_t lev0, lev1;    // levels undone by this launch, from lev1 down to lev0
     int32_t lh;            // loop bound (low-pass reconstruction length)
+    int32_t lg;            // k_inv_sym only: high-pass reconstruction length (the other kernels index both filters with l < lh)
     int32_t pend[kMaxLevels + 1];    // R_{j} is valid on buffer positions [0, pend[j]) (even)
     // k_inv_sdry only: runs of `nchunks` tiles walked right to left, `ndry` warm-up tiles, and the first
     // hlen[j] samples of R_j and W_j carried from tile to tile (hist_cap doubles of storage each)
@@ -626,6 +627,15 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
                         x.x = inrow[mod_wrap(t, n)];
                         x.y = inrow[mod_wrap(t + 1, n)];
                     }
+                } else if (MODE == kSymmetric) {
+                    // half-sample reflection: sample t < 0 is sample -t - 1 (rows of at least HALO samples)
+                    if (VEC2) {
+                        const double2 m = *reinterpret_cast<const double2*>(inrow + (-t - 2));
+                        x = make_double2(m.y, m.x);
+                    } else {
+                        x.x = inrow[-t - 1];
+                        x.y = inrow[-t - 2];
+                    }
                 }
                 *reinterpret_cast<double2*>(buf + 2 * tid) = x;
             }
@@ -682,6 +692,10 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
             }
         }
 
+        // SYMMETRIC: left of the row start V_j is the mirror image of its own first samples at EVERY level (the reference
+        // reflects the index into the level's input, internal/ScalarOps.java:827-845), which is not what recomputing
+        // from a mirrored V_{j-1} gives: the first tile of a row copies its halo from the tile after each level instead
+        const bool sym0 = (MODE == kSymmetric) && (t0 == 0);
         for (int j = a.lev0; j <= a.lev1; ++j) {
             const int s = 1 << (j - 1);
             const int ps = a.pstart[j];
@@ -692,7 +706,7 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
                 ah[0][0] = ah[0][1] = 0.0;
                 const int p = 2 * tid;
                 // halo samples are recomputed for the first tile only, and never for the last level
-                wact[0] = warm && hwave && (j < a.lev1) && (128 * wave + 128 > ps);
+                wact[0] = warm && hwave && (j < a.lev1) && (128 * wave + 128 > ps) && !sym0;
                 hwrite[0] = wact[0] && (p >= ps);
                 hbase[0] = (p >= ps ? p : ps) * 8;
             }
@@ -753,6 +767,13 @@ __global__ void __launch_bounds__(NT) k_fwd_stream(const FwdArgs a) {
                     }
                 }
                 lds_barrier();
+                if (sym0) {
+                    if (hwave) {  // V_j[-1 - i] = V_j[i]: halo pair (2 tid, 2 tid + 1) is tile pair HALO - 2 - 2 tid, swapped
+                        const double2 m = *reinterpret_cast<const double2*>(buf + HALO + (HALO - 2 - 2 * tid));
+                        *reinterpret_cast<double2*>(buf + 2 * tid) = make_double2(m.y, m.x);
+                    }
+                    lds_barrier();
+                }
             }
         }
     }

@@ -44,6 +44,11 @@ hipError_t launch_inv_carry(const InvArgs& a, int mode, bool fma, int64_t nblock
 bool inv_wave_supported(int taps, int lev0, int lev1, int mode, int64_t n);
 int inv_wave_ndry(int taps, int lev1);
 hipError_t launch_inv_wave(const InvArgs& a, int mode, bool fma, int64_t nblocks, hipStream_t stream);
+// SYMMETRIC inverse on tiles (k_inv_sym): reads left of the output sample; ppt = 1 or 4 chunks per tile, one halo chunk.
+// pairsum: MODWTTransform.inverse's arithmetic (lo*r + hi*w added as a pair, l < a.lh); otherwise the multi-level form
+// (the two products added one after the other, per-filter lengths a.lh / a.lg).  a.pend[j] = first valid halo position of R_j.
+bool inv_sym_supported(int lh, int lg, int lev0, int lev1, int64_t n);
+hipError_t launch_inv_sym(const InvArgs& a, int ppt, bool vec2, bool pairsum, int64_t nblocks, hipStream_t stream);
 hipError_t launch_fwd_sdry(const FwdArgs& a, int shape, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);
 // vec2: global access mode (0 one sample per access, 1 aligned pairs, 2 pairs at 8-byte alignment)
 hipError_t launch_inv_sdry(const InvArgs& a, int shape, int mode, int vec2, bool fma, bool unroll, int64_t nblocks, hipStream_t stream);

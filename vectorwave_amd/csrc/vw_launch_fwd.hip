@@ -30,10 +30,13 @@ static hipError_t launch_fwd_stream_pm(const FwdArgs& a, bool vec2, bool fma, bo
     if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
         return mode == kPeriodic ? launch_fwd_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
                                  : launch_fwd_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+// (SYMMETRIC: the streaming kernel only -- its first tile of a row mirrors the halo level by level)
 #define VW_FWD_STREAM_CASE(NT, P)                                                                            \
-    if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == NT)                                                        \
+    if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == NT) {                                                      \
+        if (mode == kSymmetric) return launch_fwd_stream_pm<NT, P, kSymmetric>(a, vec2, fma, unroll, nblocks, lds, stream); \
         return mode == kPeriodic ? launch_fwd_stream_pm<NT, P, kPeriodic>(a, vec2, fma, unroll, nblocks, lds, stream) \
-                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, unroll, nblocks, lds, stream);
+                                 : launch_fwd_stream_pm<NT, P, kZeroPad>(a, vec2, fma, unroll, nblocks, lds, stream); \
+    }
 
 hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, bool unroll, int64_t nblocks,
                       hipStream_t stream) {
@@ -41,6 +44,7 @@ hipError_t launch_fwd(const FwdArgs& a, TileCfg cfg, int mode, bool vec2, bool f
     VW_FWD_STREAM_CASE(256, 1)
     VW_FWD_STREAM_CASE(256, 2)
     VW_FWD_STREAM_CASE(256, 4)
+    if (mode == kSymmetric) return hipErrorInvalidValue;
     VW_FWD_CASE(4, 2)
     VW_FWD_CASE(8, 2)
     VW_FWD_CASE(8, 4)

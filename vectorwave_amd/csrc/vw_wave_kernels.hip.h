@@ -134,7 +134,6 @@ __device__ __forceinline__ void wv_addr_init(int lane, WvLevelAddr<LT>& A) {
 template <int LT, int J, int j, bool FMA, typename Post>
 __device__ __forceinline__ void wv_level(char* lds, int lane, const WvLevelAddr<LT>& A, int vswz, const double (&tl)[LT],
                                          const double (&th)[LT], bool ablate_math, Post post) {
-    constexpr int sl = j - 2;
     constexpr int rbase = (j == J) ? wv_slot_a() : 0;
     constexpr int D = wv_slot_w(J, j) - rbase;
     constexpr int HR = kWvHeads + wv_hoff(LT, j) * 16;
