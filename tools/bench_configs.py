@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
+FP64_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 39.3e12 fp64 lane-operations per second
 
 
 def main():
@@ -29,6 +30,7 @@ def main():
     import torch
     from vectorwave_amd import _native as N
     from util import dev_denoise, dev_forward, dev_inverse, dev_signals, dev_wavelet_denoise
+    from vectorwave_amd.wavelets import get_wavelet
 
     ctx = N.Context(0)
     stream = torch.cuda.current_stream()
@@ -71,12 +73,18 @@ def main():
         i_ms = timed(lambda: dev_inverse(ctx, c, wn, mode, flags, out=xr))
         samples = rows * n
         bytes_dir = 8.0 * (j + 2) * samples
+        w_ = get_wavelet(wn)
+        taps_total = len(w_.dec_lo) + len(w_.dec_hi)
         res[name] = {
             "forward_ms": round(f_ms, 4), "inverse_ms": round(i_ms, 4),
             "fwd_inv_Gsamples_per_s": round(samples / ((f_ms + i_ms) * 1e-3) / 1e9, 3),
             "forward_GBps": round(bytes_dir / (f_ms * 1e-3) / 1e9, 1),
             "inverse_GBps": round(bytes_dir / (i_ms * 1e-3) / 1e9, 1),
             "pct_of_hbm_roofline": round(100.0 * 2 * bytes_dir / ((f_ms + i_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 2),
+            # the other bound: one multiply and one add per tap and filter in the reference's arithmetic, both directions,
+            # against 256 CUs x 4 SIMDs x 16 fp64 lanes at 2.4 GHz (what decides the long-filter configurations)
+            "fp64_lane_ops_per_sample": 2 * 2 * taps_total * j,
+            "pct_of_fp64_issue": round(100.0 * 2 * 2 * taps_total * j * samples / ((f_ms + i_ms) * 1e-3) / FP64_LANE_OPS, 2),
             "max_reconstruction_error": float((xr - x).abs().max()) if mode == 0 else None,
         }
         print(name, res[name], flush=True)

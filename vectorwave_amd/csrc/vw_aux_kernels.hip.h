@@ -687,8 +687,10 @@ __device__ __forceinline__ double wg_median(const double (&v)[KPL], int64_t n, W
     return (__longlong_as_double(static_cast<long long>(v1)) + __longlong_as_double(static_cast<long long>(v2))) / 2.0;
 }
 
+// (two workgroups of 1024 lanes per CU need at most 64 registers per lane: the descent is bound by the latency of its
+// steps, so the second row in flight counts for more than a few moves around the sixteen keys of a lane)
 template <int NT, int KPL>
-__global__ void __launch_bounds__(NT) k_universal_threshold_wg(const MedianArgs a) {
+__global__ void __launch_bounds__(NT, (KPL <= 16 && NT == 1024) ? 8 : 1) k_universal_threshold_wg(const MedianArgs a) {
     constexpr int NW = NT / 64;
     __shared__ WgCells cells;
     int par = 0;  // next unused exchange cell
@@ -1049,7 +1051,7 @@ __global__ void __launch_bounds__(64) k_swt_denoise_row(const RowDenoiseArgs a) 
 // place (the forward looks left, so its chunks are taken right to left; the inverse the other way round).  LDS per
 // row drops from about 26 KiB to 9 KiB, i.e. from 6 to 12 resident rows per CU (then bounded by registers).
 template <int LT, int MODE>
-__global__ void __launch_bounds__(64) k_swt_denoise_rowreg(const RowDenoiseArgs a) {
+__global__ void __launch_bounds__(64, 3) k_swt_denoise_rowreg(const RowDenoiseArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ double2 vw_smem[];
     constexpr int KP = 4, JMAX = 4;
