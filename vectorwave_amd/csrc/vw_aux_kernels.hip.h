@@ -1068,13 +1068,11 @@ __global__ void __launch_bounds__(64, 3) k_swt_denoise_rowreg(const RowDenoiseAr
     const int64_t row = blockIdx.x;
     const double* __restrict__ xrow = a.x + row * a.x_stride;
 
-    double dl[LT], dh[LT], rl[LT], rh[LT];
+    double dl[LT], dh[LT];  // (the reconstruction taps are fetched where the inverse cascade starts: scalar registers)
 #pragma unroll
     for (int l = 0; l < LT; ++l) {
         dl[l] = a.dec.lo[l];
         dh[l] = a.dec.hi[l];
-        rl[l] = a.rec.lo[l];
-        rh[l] = a.rec.hi[l];
     }
     auto fill_left = [&](double* b, int H) {
         for (int i = lane; i < H; i += 64) b[-1 - i] = (MODE == kPeriodic) ? b[n - 1 - i] : 0.0;
@@ -1127,7 +1125,13 @@ __global__ void __launch_bounds__(64, 3) k_swt_denoise_rowreg(const RowDenoiseAr
         return __builtin_amdgcn_readfirstlane(static_cast<int>(calm && thr >= 0.0 && thr <= 0x1.fffffffffffffp1023)) != 0;
     };
     bool quick = quick_now();
-    auto shrink = [&](double c) -> double { return quick ? shrink_finite(c, thr, soft) : apply_thr(c, thr, a.thr_mode); };
+    // `quick` is wave-uniform: the general rule stays behind a scalar branch (the empty asm keeps the compiler from
+    // evaluating both forms for every coefficient and selecting afterwards)
+    auto shrink = [&](double c) -> double {
+        if (quick) return shrink_finite(c, thr, soft);
+        asm volatile("" ::: "memory");
+        return apply_thr(c, thr, a.thr_mode);
+    };
     double wreg[JMAX][KP][2];
     // ---- forward cascade, in place, chunk groups right to left ---------------------------------------------
 #pragma unroll
@@ -1228,6 +1232,12 @@ __global__ void __launch_bounds__(64, 3) k_swt_denoise_rowreg(const RowDenoiseAr
 
     // ---- inverse cascade, in place, chunks left to right ------------------------------------------------------
     double* __restrict__ yrow = a.y + row * a.y_stride;
+    double rl[LT], rh[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+        rl[l] = a.rec.lo[l];
+        rh[l] = a.rec.hi[l];
+    }
 #pragma unroll
     for (int j = JMAX; j >= 1; --j) {
         if (j <= J) {
