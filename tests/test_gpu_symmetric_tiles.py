@@ -5,8 +5,9 @@ first samples after every level (the reference reflects the index into each leve
 internal/ScalarOps.java:827-845, util/MathUtils.java:31-52).  Inverse: k_inv_sym, the left-looking tile kernel of the
 reference's SYMMETRIC reconstruction (modwt/MultiLevelMODWTTransform.java:664-685: reflect(t - l s), the two products
 added one after the other, per-filter lengths) and of MODWTTransform.inverse (modwt/MODWTTransform.java:269-287: pair
-sum).  inverseBatchOptimized's flavour (reflects t + l, :644-657), rows shorter than one chunk and level groups whose
-context exceeds a chunk stay with the generic one-level kernels; `no_sym_tiles` forces those everywhere."""
+sum).  inverseBatchOptimized's flavour (reflects t + l at the row end, :644-657) is the ordinary single-level tile kernel
+with a mirrored right halo.  Rows shorter than one chunk and level groups whose context exceeds a chunk stay with the
+generic one-level kernels; `no_sym_tiles` forces those everywhere."""
 import ctypes as C
 
 import numpy as np
@@ -76,7 +77,8 @@ def test_symmetric_tiles_equal_the_generic_kernels(ctx, plan):
     assert_bits_equal(tback, gback, "inverse")
 
 
-@pytest.mark.parametrize("wn,n,b", [("db4", 4096, 6), ("db4", 1000, 5), ("haar", 777, 4), ("bior2.2", 2048, 4), ("db4", 4097, 4)])
+@pytest.mark.parametrize("wn,n,b", [("db4", 4096, 6), ("db4", 1000, 5), ("haar", 777, 4), ("bior2.2", 2048, 4), ("db4", 4097, 4),
+                                    ("db4", 512, 3), ("sym8", 5000, 3), ("db10", 2049, 2), ("rbio2.4", 3000, 2)])
 def test_symmetric_single_level_through_tiles(ctx, wn, n, b):
     """MODWTTransform.forward / inverse (reflects t - l, pair sum) on tiles; the batch flavour of the inverse (t + l) not."""
     w = get_wavelet(wn)
@@ -93,7 +95,8 @@ def test_symmetric_single_level_through_tiles(ctx, wn, n, b):
         assert_bits_equal(back, o.modwt_inverse_batch(want, w, S, batch_variant=0), "inverse()")
         st, back2, _ = gpu_inverse(ctx, want, wn, S, N.VW_FLAG_SINGLE_LEVEL | N.VW_FLAG_SYMMETRIC_BATCH_VARIANT)
         assert st == 0, ctx.last_error()
-        assert "k_inv_sym" not in ctx.last_plan(), ctx.last_plan()
+        # (reflects t + l at the row END: the ordinary right-looking tile kernel with a mirrored halo)
+        assert ("k_inv_fused" in ctx.last_plan()) == (n >= 512), ctx.last_plan()
         assert_bits_equal(back2, o.modwt_inverse_batch(want, w, S, batch_variant=1), "inverseBatchOptimized()")
 
 

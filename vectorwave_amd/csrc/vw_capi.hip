@@ -938,9 +938,11 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
     const double* aslot = coeffs + static_cast<int64_t>(levels) * n;
 
     // SYMMETRIC: the left-looking tile kernel (k_inv_sym) for the multi-level form and for MODWTTransform.inverse;
-    // inverseBatchOptimized's flavour (reflects t + l) stays with the generic kernel
+    // inverseBatchOptimized's flavour (reflects t + l at the row end, pair sum) is the ordinary single-level tile
+    // kernel with a mirrored right halo
     const bool sym = (boundary == VW_BOUNDARY_SYMMETRIC);
-    bool generic_all = sym && (n < kChunk || ctx->opt.no_sym_tiles || (single && (flags & VW_FLAG_SYMMETRIC_BATCH_VARIANT)));
+    const bool sym_right = sym && single && (flags & VW_FLAG_SYMMETRIC_BATCH_VARIANT) != 0;
+    bool generic_all = sym && (n < kChunk || ctx->opt.no_sym_tiles);
     if (!single) {
         for (int j = 1; j <= levels; ++j) {
             const int64_t s = static_cast<int64_t>(1) << (j - 1);
@@ -960,7 +962,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             st.cfg = TileCfg{0, 0, kThreads};
             // a context beyond one chunk: as many of the remaining levels as fit one pass of the
             // long-context streaming kernel
-            if (!generic_all && sym) {
+            if (!generic_all && sym && !sym_right) {
                 // as many of the remaining levels as keep their joint left context inside one halo chunk
                 if (inv_sym_supported(lhr, lgr, j, j, n)) {
                     int lo = j;
@@ -987,7 +989,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             }
             if (!generic_all) {
                 TileCfg cfg;
-                if (pick_cfg(ctx, n, inv_halo(j, j, lhr), inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg)) {
+                if (pick_cfg(ctx, n, inv_halo(j, j, lhr), inv_cfgs((flags & VW_FLAG_FMA) != 0), &cfg) && (!sym || cfg.hpt == 1)) {
                     st.fused = true;
                     st.cfg = cfg;
                     int lo = j;
@@ -1067,7 +1069,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             plan_note(ctx->plan_inv, "k_inv_sdry", st.lev0, st.lev1);
             hipError_t e = launch_inv_sdry(a, st.sdry, boundary, ctx->opt.inv_vm >= 0 ? (ctx->opt.inv_vm == 1 && !vec2 ? 2 : ctx->opt.inv_vm) : (vec2 ? 1 : 2), (flags & VW_FLAG_FMA) != 0, ctx->opt.no_unroll == 0, nblocks, stream);
             if (e != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(e));
-        } else if (st.fused && sym) {
+        } else if (st.fused && sym && !sym_right) {
             InvArgs a;
             memset(&a, 0, sizeof(a));
             a.rin = rin;
@@ -1157,7 +1159,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                               !ctx->opt.no_vec2;
             const int64_t nblocks = b * a.ntiles;
             if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
-            const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1);
+            const bool blk = st.cfg.ppt == 4 && st.cfg.hpt == 1 && !ctx->opt.no_blk && inv_blk_supported(a.lh, st.lev1) && !sym;
             const bool ring = blk && vec2 && n >= 2560 && !ctx->opt.no_ring && ctx->lds_limit >= 81920;
             // opt-in: runs of tiles with carried right contexts
             bool carry = ring && ctx->opt.carry_chunks >= 2 && a.ntiles > 1 && inv_carry_supported(a.lh, st.lev0, st.lev1);
@@ -1210,7 +1212,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                             : carry ? launch_inv_carry(a, boundary, (flags & VW_FLAG_FMA) != 0, nlaunch, stream)
                             : ring ? launch_inv_ring(a, boundary, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
                             : blk ? launch_inv_blk(a, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream)
-                                  : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0, nblocks, stream);
+                                  : launch_inv(a, st.cfg, boundary, vec2, (flags & VW_FLAG_FMA) != 0 && !sym, nblocks, stream);
             if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "inverse kernel launch: %s", hipGetErrorString(er));
         } else {
             if (first && first_bad_cell != nullptr)

@@ -1017,20 +1017,34 @@ __device__ __forceinline__ void inv_fetch(const double* __restrict__ src, bool u
         double2 x = make_double2(0.0, 0.0);
         if (use && p < plimit) {
             const int64_t t = t0 + p;
+            // kSymmetric (single-level launches only: MODWTTransform.inverseBatchOptimized reflects t + l at the row end,
+            // modwt/MODWTTransform.java:644-657): sample t >= n is sample 2n - 1 - t; rows of at least one chunk
             if (VEC2) {
-                if (t < n)
+                if (t < n) {
                     x = *reinterpret_cast<const double2*>(src + t);
-                else if (MODE == kPeriodic)
+                } else if (MODE == kPeriodic) {
                     x = *reinterpret_cast<const double2*>(src + mod_wrap(t, n));
+                } else if (MODE == kSymmetric) {
+                    // (a tile that starts near the row end reaches beyond the mirror image of the whole row: nothing
+                    // that is stored depends on those positions, and nothing may be read for them)
+                    if (t <= 2 * n - 2) {
+                        const double2 m = *reinterpret_cast<const double2*>(src + (2 * n - 2 - t));
+                        x = make_double2(m.y, m.x);
+                    }
+                }
             } else {
                 if (t < n)
                     x.x = src[t];
                 else if (MODE == kPeriodic)
                     x.x = src[mod_wrap(t, n)];
+                else if (MODE == kSymmetric && t <= 2 * n - 1)
+                    x.x = src[2 * n - 1 - t];
                 if (t + 1 < n)
                     x.y = src[t + 1];
                 else if (MODE == kPeriodic)
                     x.y = src[mod_wrap(t + 1, n)];
+                else if (MODE == kSymmetric && t <= 2 * n - 2)
+                    x.y = src[2 * n - 2 - t];
             }
         }
         v[c] = x;

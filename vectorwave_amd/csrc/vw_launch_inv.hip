@@ -16,9 +16,22 @@ static hipError_t launch_inv_pm(const InvArgs& a, bool vec2, bool fma, int64_t n
     if (cfg.ppt == P && cfg.hpt == H && cfg.nt == kThreads)                                                  \
         return mode == kPeriodic ? launch_inv_pm<P, H, kPeriodic>(a, vec2, fma, nblocks, lds, stream)        \
                                  : launch_inv_pm<P, H, kZeroPad>(a, vec2, fma, nblocks, lds, stream);
+// SYMMETRIC: single-level launches with the mirrored right halo (reference arithmetic only), one halo chunk
+#define VW_INV_SYM_CASE(P)                                                                                    \
+    if (cfg.ppt == P && cfg.hpt == 1 && cfg.nt == kThreads)                                                   \
+        return vec2 ? launch_tile(k_inv_fused<P, 1, kSymmetric, true, false>, a, nblocks, lds, stream)        \
+                    : launch_tile(k_inv_fused<P, 1, kSymmetric, false, false>, a, nblocks, lds, stream);
 hipError_t launch_inv(const InvArgs& a, TileCfg cfg, int mode, bool vec2, bool fma, int64_t nblocks,
                              hipStream_t stream) {
     const size_t lds = cfg.lds_bytes(true);
+    if (mode == kSymmetric) {
+        if (a.lev0 != 1 || a.lev1 != 1) return hipErrorInvalidValue;
+        VW_INV_SYM_CASE(1)
+        VW_INV_SYM_CASE(2)
+        VW_INV_SYM_CASE(4)
+        VW_INV_SYM_CASE(8)
+        return hipErrorInvalidValue;
+    }
     VW_INV_CASE(1, 1)
     VW_INV_CASE(2, 1)
     VW_INV_CASE(4, 1)
