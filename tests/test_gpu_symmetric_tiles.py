@@ -180,3 +180,35 @@ def test_symmetric_many_rows_many_tiles(ctx):
     st, back, _ = gpu_inverse(ctx, want, "db4", S)
     assert st == 0, ctx.last_error()
     assert_bits_equal(back, o.reconstruct_batch(want, w, S), "inverse 40 x 32768")
+
+
+@pytest.mark.parametrize("method", ["UNIVERSAL", "MINIMAX", "BAYES"])
+@pytest.mark.parametrize("soft", [True, False])
+@pytest.mark.parametrize("levels", [0, 5])
+def test_symmetric_wavelet_denoiser_thresholds_on_load(ctx, method, soft, levels):
+    """WaveletDenoiser with SYMMETRIC (denoising/WaveletDenoiser.java:121-227): the per-level thresholds are applied as
+    k_inv_sym stages the bands (levels == 0: the single-level form, MODWTTransform.inverse's pair sum)."""
+    import torch
+    from util import dev_wavelet_denoise
+    w = get_wavelet("db4")
+    x = signals(3, 5000, seed=61)
+    x[1, 777] = 3.0e3  # an outlier that survives every threshold
+    m = getattr(o, method)
+    st, want, wthr = o.wavelet_denoise_batch(x, w, levels, m, soft, S)
+    assert st == 0
+    got, thr = dev_wavelet_denoise(ctx, torch.from_numpy(x).cuda(), "db4", levels, S, getattr(N, "VW_THRESHOLD_" + method), soft)
+    assert "k_inv_sym" in ctx.last_plan() and "k_fwd_stream" in ctx.last_plan(), ctx.last_plan()
+    assert_bits_equal(thr.cpu().numpy(), wthr, "thresholds")
+    assert_bits_equal(got.cpu().numpy(), want, "SYMMETRIC WaveletDenoiser %s levels=%d" % (method, levels))
+
+
+@pytest.mark.parametrize("thr,soft", [(float("nan"), True), (float("inf"), False), (0.0, True)])
+def test_symmetric_swt_denoise_odd_thresholds(ctx, thr, soft):
+    w = get_wavelet("sym4")
+    x = signals(2, 4098, seed=71)
+    st, want = o.swt_denoise_batch(x, w, 6, thr, soft, S)
+    assert st == 0
+    st, got, _ = gpu_denoise(ctx, x, "sym4", 6, S, thr, soft)
+    assert st == N.VW_OK, ctx.last_error()
+    assert "k_inv_sym" in ctx.last_plan(), ctx.last_plan()
+    assert_bits_equal(got, want, "SYMMETRIC swt denoise, threshold %r" % thr)

@@ -925,6 +925,15 @@ extern "C" int32_t vw_modwt_forward_batch(vw_ctx* ctx, const double* x, int64_t 
 // inverse
 // ---------------------------------------------------------------------------
 
+// SYMMETRIC: every level of the cascade goes through the left-looking tile kernel -- then a denoise applies its
+// thresholds as that kernel stages the bands, instead of in a pass of its own over the coefficient block
+static bool sym_inverse_all_tiled(const vw_ctx* ctx, int lhr, int lgr, int levels, int64_t n) {
+    if (n < kChunk || ctx->opt.no_sym_tiles) return false;
+    for (int j = 1; j <= levels; ++j)
+        if (!inv_sym_supported(lhr, lgr, j, j, n)) return false;
+    return true;
+}
+
 static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, int levels, const double* hr, int lhr,
                        const double* gr, int lgr, int boundary, uint32_t flags, uint32_t band_mask, int thr_mode,
                        const double* thr_rows, double* xout, unsigned long long* first_bad_cell, hipStream_t stream,
@@ -949,7 +958,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             if (truncated_taps(lhr, s, n) != lhr || truncated_taps(lgr, s, n) != lgr) generic_all = true;
         }
     }
-    if ((generic_all || sym) && thr_mode != 0) return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
+    if (thr_mode != 0 && (generic_all || (sym && (sym_right || !sym_inverse_all_tiled(ctx, lhr, lgr, levels, n)))))
+        return set_err(ctx, VW_E_HIP, "internal: thresholded inverse needs the fused path");
 
     StepList steps;
     {
@@ -1098,7 +1108,10 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                 a.pend[j - 1] = static_cast<int32_t>(v < kChunk ? v : kChunk);
             }
             a.band_mask = (band_mask & 0x7fffffffu) | (use_rin ? 0x80000000u : 0u);
-            a.thr_mode = 0;
+            a.thr_mode = thr_mode;
+            a.thr = thr_rows;
+            a.thr_row_stride = thr_row_stride;
+            a.thr_level_stride = thr_level_stride;
             a.first_bad = first_bad_cell;
             a.check_rin = first ? 1 : 0;
             a.taps = taps;
@@ -1734,8 +1747,8 @@ static int swt_denoise_run(vw_ctx* ctx, const double* x_dev, int64_t b, int64_t 
         VW_HIP(ctx, hipMemcpyAsync(thresholds_out_dev, thr, static_cast<size_t>(b) * 8, hipMemcpyDeviceToDevice, s));
     const int mode = soft ? 1 : 2;
     // fused inverse thresholds the detail bands as they are loaded; the generic
-    // path (SYMMETRIC, truncated filters) thresholds the block in place first
-    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
+    // path (SYMMETRIC levels outside the tile kernel, truncated filters) thresholds the block in place first
+    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC) && !sym_inverse_all_tiled(ctx, lhr, lgr, levels, n);
     for (int j = 1; j <= levels; ++j) {
         const int64_t st = static_cast<int64_t>(1) << (j - 1);
         if (truncated_taps(lhr, st, n) != lhr || truncated_taps(lgr, st, n) != lgr) generic = true;
@@ -1883,7 +1896,7 @@ static int threshold_inverse_dev(vw_ctx* ctx, double* coeffs, int64_t b, int64_t
                                  double* y_dev, hipStream_t s) {
     const bool single = (tflags & VW_FLAG_SINGLE_LEVEL) != 0;
     const int mode = soft ? 3 : 2;  // WaveletDenoiser.applyThreshold: the `abs <= thr ? 0.0 : ...` form
-    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC);
+    bool generic = (boundary == VW_BOUNDARY_SYMMETRIC) && !sym_inverse_all_tiled(ctx, lhr, lgr, levels, n);
     if (!single) {
         for (int j = 1; j <= levels; ++j) {
             const int64_t st = static_cast<int64_t>(1) << (j - 1);

@@ -116,7 +116,8 @@ __device__ __forceinline__ void sym_pair(const double* __restrict__ bufR, const 
 
 // a.pend[j]: first halo position (even) from which R_j is valid; a.lh / a.lg: taps of lo / hi.
 // Buffer position p <-> sample t0 - 512 + p.
-template <int PPT, bool VEC2, bool PAIRSUM, int LT>
+// THR: a.thr_mode (a mode of apply_thr) is applied to W_j as it is staged, with the threshold of (row, level j).
+template <int PPT, bool VEC2, bool PAIRSUM, int LT, bool THR = false>
 __global__ void __launch_bounds__(kThreads) k_inv_sym(const InvArgs a) {
     extern __shared__ double2 vw_smem[];
     constexpr int HALO = kChunk;
@@ -160,10 +161,18 @@ __global__ void __launch_bounds__(kThreads) k_inv_sym(const InvArgs a) {
             if (t + 1 < n && !finite_f64(pre[k].y)) atomicMin(a.first_bad, static_cast<unsigned long long>(flat0 + t + 1));
         }
     };
-    // W_j from the registers into LDS, then W_{j-1} on its way while level j is computed
-    // (no thresholding here: a SYMMETRIC denoise thresholds the coefficient block in a pass of its own)
+    // W_j from the registers into LDS (thresholded on the way when denoising: the rule is element-wise, so the mirrored
+    // halo agrees with the tile), then W_{j-1} on its way while level j is computed
     auto publish = [&](int j) {
         if (a.first_bad != nullptr) check(j - 1);
+        if (THR) {
+            const double thr = uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride);
+#pragma unroll
+            for (int k = 0; k <= PPT; ++k) {
+                pre[k].x = apply_thr(pre[k].x, thr, a.thr_mode);
+                pre[k].y = apply_thr(pre[k].y, thr, a.thr_mode);
+            }
+        }
 #pragma unroll
         for (int k = 0; k <= PPT; ++k) *reinterpret_cast<double2*>(bufW + (k < PPT ? HALO + k * kChunk : 0) + 2 * tid) = pre[k];
         lds_barrier();  // R_j and W_j visible
