@@ -115,3 +115,15 @@ def test_wave_wavelet_denoiser_bit_exact(ctx, plan, method, soft):
     assert "k_inv_wave" in ctx.last_plan(), ctx.last_plan()
     assert_bits_equal(thr.cpu().numpy(), wthr, "thresholds")
     assert_bits_equal(got.cpu().numpy(), want, "WaveletDenoiser %s through the wave kernel" % method)
+
+
+@pytest.mark.parametrize("mode", [P, Z])
+@pytest.mark.parametrize("n", [2050, 2178, 2306, 2434, 3074])
+def test_wave_partial_last_chunk_under_load(ctx, plan, n, mode):
+    """Rows whose last chunk holds 2, 130, 258 or 386 samples: the chunk issues one to four store instructions, and the
+    counted waits of the chunk after it allow for exactly that many.  (A wait that allowed for four let the next chunk
+    start before its first bands had landed -- rarely: 600 rows keep every CU busy with waves in different phases.)"""
+    plan("inv_wave", 3)
+    got, want, _ = _inverse_case(ctx, "db4", n, 6, 600, mode, seed=n)
+    assert "k_inv_wave" in ctx.last_plan(), ctx.last_plan()
+    assert_bits_equal(got, want, "wave inverse, partial last chunk, N=%d mode %d" % (n, mode))

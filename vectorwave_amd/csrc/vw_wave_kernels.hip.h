@@ -82,19 +82,27 @@ __device__ __forceinline__ void wv_issue(const double* __restrict__ band_row, in
 // 16-byte store to a wave-uniform base plus a 32-bit byte offset per lane.  Written out so that the address stays an SGPR
 // pair and one VGPR: left to the compiler, the per-lane 64-bit address of the output row lives in a register pair across
 // the whole chunk loop (and was spilled: a scratch reload per chunk, with a full vmcnt(0) drain in front of it).
+// The s_nop belongs to the store: a store of more than 64 bits reads its data registers up to two wait states after it
+// issues, and a VALU instruction that overwrites one of them inside that window changes what is stored.  The compiler
+// keeps that distance for its own stores but does not look inside inline assembly, and it reuses the data registers,
+// dead after this statement, at once (seen: the index of the next block's bounds test written into the first data
+// register one instruction later -- the low half of one double of a few lanes came out as that index, now and then).
 __device__ __forceinline__ void wv_store16(double* sbase, unsigned voff, double2 v, int nt) {
     vw_f64x2 x;
     x.x = v.x;
     x.y = v.y;
     if (nt)
-        asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
     else
-        asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
 }
 
 __device__ __forceinline__ void wv_wait_vm(int n) {  // n is wave-uniform
     switch (n) {
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -437,9 +445,9 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
         issue(wband(4), t0, 2, vs2, wv_slot_w(J, 4));
     }
 
+    int pst = 0;  // store instructions of the previous chunk that the memory counter may still hold
     for (int st = 0; st < nsteps; ++st) {
         const bool dry = st < ndry, last = (st + 1 == nsteps);
-        const int pst = (st > ndry) ? 4 : 0;  // the previous chunk's four stores are still counted
         const int64_t t0 = chunk_t0(st);
         const int64_t tn = last ? 0 : chunk_t0(st + 1);
         const bool pf = !last;
@@ -478,16 +486,23 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
                 issue(wband(4), tn, 2, vs2, wv_slot_w(J, 4));
             }
         });
+        // The counted waits of the next chunk allow for the store instructions issued here, so their number must be
+        // exact: a 64-pair block of the partial chunk that lies wholly outside the row issues NO instruction (the
+        // compiler branches around a store whose lanes are all off), and a wait that allowed for it would let the
+        // next chunk's levels start before their bands have landed.
+        pst = 0;
         if (!dry && t0 < a.n_store) {
             double* __restrict__ cb = orow + t0;  // wave-uniform
             if (t0 + kWvSamples <= n) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) wv_store16(cb, static_cast<unsigned>(vsid + 1024 * kk), make_double2(out[kk][0], out[kk][1]), a.nt_store);
+                pst = 4;
             } else {  // the last, partial chunk of the row
                 const int rem = static_cast<int>(n - t0);  // samples of the chunk inside the row (< 512)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     if (2 * (kk * 64 + lane) < rem) wv_store16(cb, static_cast<unsigned>(vsid + 1024 * kk), make_double2(out[kk][0], out[kk][1]), a.nt_store);
+                pst = (rem + 127) >> 7;  // blocks with at least one pair inside the row
             }
         }
     }
