@@ -137,7 +137,8 @@ int32_t vw_device_count(void);
  * size, 0, 1), "inv_wave" (one wavefront per run of 512-sample chunks for the six-level inverse: 0 = where it pays,
  * -1 = never, N = wherever it applies with runs of N chunks) / "inv_wave_nt" (-1, 0, 1: its band loads carry the
  * streaming hint), "no_sym_tiles" (0/1: SYMMETRIC through the one-level kernels instead of the tile kernels),
- * "reset" (all defaults).  Unknown names return VW_E_UNSUPPORTED. */
+ * "no_soa_runs" (0/1: the structure-of-arrays transform one output per lane) / "soa_run_len" (8, 16, 32: samples per
+ * lane of its register-window kernel; 0 = default), "reset" (all defaults).  Unknown names return VW_E_UNSUPPORTED. */
 int32_t vw_set_plan_option(vw_ctx *ctx, const char *name, int64_t value);
 /* The kernels that the context's last forward and last inverse call enqueued, as text
  * ("forward: k_fwd_stream[1-6]; inverse: k_inv_ring[1-6]": kernel family and the levels each launch covers; a

@@ -86,6 +86,30 @@ def test_gpu_soa_batch_bit_exact(ctx, wn, b, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("run_len", [0, 8, 16, 32, -1])
+@pytest.mark.parametrize("wn,b,n", [("haar", 1024, 100), ("haar", 515, 33), ("db2", 1030, 70), ("db4", 2048, 129), ("db4", 777, 40),
+                                    ("coif1", 600, 50), ("db6", 514, 64), ("sym8", 1000, 90), ("db10", 520, 77), ("sym9", 300, 60), ("sym5", 258, 41), ("sym7", 512, 30), ("sym11", 300, 50),
+                                    ("db4", 6, 5000)])
+def test_gpu_soa_run_kernel_variants(ctx, plan, wn, b, n, run_len):
+    """The register-window kernel (8, 16 or 32 samples per lane; pairs of signals per lane when the batch is even, single
+    signals when it is odd) and the one-output-per-lane kernel (run_len -1) give the oracle's bits: several blocks along
+    the batch, several along time, the first block wrapping around the row end (modwt/BatchSIMDMODWT.java:86-274)."""
+    from vectorwave_amd import BatchSIMDMODWT
+    if run_len < 0:
+        plan("no_soa_runs", 1)
+    elif run_len > 0:
+        plan("soa_run_len", run_len)
+    w = get_wavelet(wn)
+    x = signals(b, n, seed=b + n)
+    soa = o.convert_to_soa(x)
+    a, d = np.empty(b * n), np.empty(b * n)
+    BatchSIMDMODWT.batchMODWTSoA(soa, a, d, w, b, n, ctx)
+    wa, wd = o.batch_modwt_soa(soa, w, b, n)
+    assert_bits_equal(a, wa, "soaApprox %s %d x %d" % (wn, b, n))
+    assert_bits_equal(d, wd, "soaDetail %s %d x %d" % (wn, b, n))
+
+
+@pytest.mark.gpu
 def test_gpu_soa_unequal_filter_lengths_rejected(ctx):
     # generalBatchMODWTSoA loops l < lowPass.length over highPass too (BatchSIMDMODWT.java:240-249): with
     # bior4.4 (9 / 7 taps) the reference indexes out of bounds; the library reports it instead

@@ -59,6 +59,8 @@ struct PlanOptions {
     int no_band_regs = 0;                // 1: the row-resident denoise keeps every detail band in LDS
     int no_vec2 = 0;                     // 1: the inverse tile kernels access global memory one sample at a time
     int no_sym_tiles = 0;                // 1: SYMMETRIC always through the generic one-level kernels
+    int no_soa_runs = 0;                 // 1: the structure-of-arrays transform one output per lane (k_soa_modwt)
+    int soa_run_len = 0;                 // samples per lane of k_soa_modwt_run: 8, 16 or 32; 0 = default
 #ifdef VW_TUNING
     char ablate[64] = {0};               // tuning build only: switches parts of a kernel off (wrong results)
 #endif
@@ -225,6 +227,10 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
         o.no_band_regs = value != 0;
     } else if (strcmp(name, "no_sym_tiles") == 0) {
         o.no_sym_tiles = value != 0;
+    } else if (strcmp(name, "no_soa_runs") == 0) {
+        o.no_soa_runs = value != 0;
+    } else if (strcmp(name, "soa_run_len") == 0) {
+        o.soa_run_len = (value == 8 || value == 16 || value == 32) ? static_cast<int>(value) : 0;
     } else {
         return set_err(ctx, VW_E_UNSUPPORTED, "unknown plan option '%s'", name);
     }
@@ -236,7 +242,7 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
 // and VW_ABLATE switches parts of the kernels off to time what is left -- with wrong results.
 static void tuning_env(vw_ctx* ctx) {
     static const char* const names[] = {"fwd_chunks", "stream_wgs", "sdry_chunks", "no_sdry", "nt_stores", "no_unroll",
-                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "inv_wave_nt", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs", "no_sym_tiles"};
+                                        "no_reg_select", "no_wg_select", "select_lds_cap", "no_std_chains", "no_row_denoise", "no_blk", "no_ring", "inv_wave", "inv_wave_nt", "carry_chunks", "no_wide_inv", "inv_vm", "no_vec2", "no_band_regs", "no_sym_tiles", "no_soa_runs", "soa_run_len"};
     for (const char* nm : names) {
         char env[64] = "VW_";
         size_t k = 3;
@@ -2501,6 +2507,56 @@ extern "C" int32_t vw_transpose(vw_ctx* ctx, const double* in, int64_t rows, int
     return VW_OK;
 }
 
+// k_soa_modwt_run exists for the Haar constants, the four-tap chain and the general form with an even number of taps up
+// to 20; anything else stays with k_soa_modwt
+static bool soa_run_supported(int flavour, int lh) {
+    if (flavour == 1) return true;
+    if (flavour == 2) return lh == 4;
+    return lh >= 2 && lh <= 20 && lh % 2 == 0;
+}
+
+template <int L, int FLAV, int T>
+static hipError_t launch_soa_run_t(const SoaArgs& a, bool vec2, hipStream_t stream) {
+    const int64_t per_block = static_cast<int64_t>(kThreads) * (vec2 ? 2 : 1);
+    const int64_t bchunks = (a.batch + per_block - 1) / per_block;
+    const int64_t ttiles = (a.n + T - 1) / T;
+    if (bchunks > 0x7fffffffLL / ttiles) return hipErrorInvalidConfiguration;
+    const unsigned nblocks = static_cast<unsigned>(bchunks * ttiles);
+    if (vec2)
+        hipLaunchKernelGGL((k_soa_modwt_run<L, FLAV, T, 2>), dim3(nblocks), dim3(kThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_soa_modwt_run<L, FLAV, T, 1>), dim3(nblocks), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+template <int L, int FLAV>
+static hipError_t launch_soa_run_l(const SoaArgs& a, bool vec2, int run_len, hipStream_t stream) {
+    // the window is T + L - 1 samples (times two signals) in registers: long filters take the shorter run
+    if (run_len == 0) run_len = L <= 12 ? 16 : 8;
+    if (run_len == 32 && L <= 12) return launch_soa_run_t<L, FLAV, 32>(a, vec2, stream);
+    if (run_len >= 16 && L <= 12) return launch_soa_run_t<L, FLAV, 16>(a, vec2, stream);
+    if (run_len >= 16) return launch_soa_run_t<L, FLAV, 16>(a, vec2, stream);
+    return launch_soa_run_t<L, FLAV, 8>(a, vec2, stream);
+}
+
+static hipError_t launch_soa_run(const SoaArgs& a, bool vec2, int run_len, hipStream_t stream) {
+    if (a.flavour == 1) return launch_soa_run_l<2, 1>(a, vec2, run_len, stream);
+    if (a.flavour == 2) return launch_soa_run_l<4, 2>(a, vec2, run_len, stream);
+    switch (a.flen) {
+        case 2: return launch_soa_run_l<2, 0>(a, vec2, run_len, stream);
+        case 4: return launch_soa_run_l<4, 0>(a, vec2, run_len, stream);
+        case 6: return launch_soa_run_l<6, 0>(a, vec2, run_len, stream);
+        case 8: return launch_soa_run_l<8, 0>(a, vec2, run_len, stream);
+        case 10: return launch_soa_run_l<10, 0>(a, vec2, run_len, stream);
+        case 12: return launch_soa_run_l<12, 0>(a, vec2, run_len, stream);
+        case 14: return launch_soa_run_l<14, 0>(a, vec2, run_len, stream);
+        case 16: return launch_soa_run_l<16, 0>(a, vec2, run_len, stream);
+        case 18: return launch_soa_run_l<18, 0>(a, vec2, run_len, stream);
+        case 20: return launch_soa_run_l<20, 0>(a, vec2, run_len, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 static int soa_checks(vw_ctx* ctx, const void* in, const void* a, const void* d, int64_t batch, int64_t n, const double* h, int lh,
                       const double* g, int lg) {
     if (ctx == nullptr) return VW_E_NULL;
@@ -2532,6 +2588,13 @@ extern "C" int32_t vw_batch_modwt_soa_dev(vw_ctx* ctx, const double* soa_signals
     a.flavour = is_haar ? 1 : (lh == 4 ? 2 : 0);
     scale_taps(h, lh, a.taps.lo);
     scale_taps(g, lh, a.taps.hi);
+    if (!ctx->opt.no_soa_runs && soa_run_supported(a.flavour, lh)) {
+        const bool vec2 = batch % 2 == 0 && aligned16(soa_signals_dev) && aligned16(soa_approx_dev) && aligned16(soa_detail_dev);
+        const hipError_t er = launch_soa_run(a, vec2, ctx->opt.soa_run_len, static_cast<hipStream_t>(stream));
+        if (er == hipErrorInvalidConfiguration) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
+        if (er != hipSuccess) return set_err(ctx, VW_E_HIP, "structure-of-arrays kernel launch: %s", hipGetErrorString(er));
+        return VW_OK;
+    }
     const int64_t nblocks = (batch * n + kThreads - 1) / kThreads;
     if (nblocks > 0x7fffffffLL) return set_err(ctx, VW_E_TOO_LARGE, "grid too large");
     hipLaunchKernelGGL(k_soa_modwt, dim3(static_cast<unsigned>(nblocks)), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
