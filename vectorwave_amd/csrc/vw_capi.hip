@@ -194,7 +194,11 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
     } else if (strcmp(name, "no_sdry") == 0) {
         o.no_sdry = value != 0;
     } else if (strcmp(name, "nt_stores") == 0) {
+#ifdef VW_TUNING
+        o.nt_stores = value < 0 ? -1 : static_cast<int>(value & 7);  // tuning build: k_inv_wave6 knows other policy bits
+#else
         o.nt_stores = value < 0 ? -1 : (value != 0);
+#endif
     } else if (strcmp(name, "no_unroll") == 0) {
         o.no_unroll = value != 0;
     } else if (strcmp(name, "no_reg_select") == 0) {
@@ -214,7 +218,11 @@ extern "C" int32_t vw_set_plan_option(vw_ctx* ctx, const char* name, int64_t val
     } else if (strcmp(name, "inv_wave") == 0) {
         o.inv_wave = value > 0 ? static_cast<int>(value < 1000000 ? value : 1000000) : (value < 0 ? -1 : 0);
     } else if (strcmp(name, "inv_wave_nt") == 0) {
+#ifdef VW_TUNING
+        o.inv_wave_nt = value < 0 ? -1 : static_cast<int>(value & 7);  // tuning build: any combination of the policy bits
+#else
         o.inv_wave_nt = value < 0 ? -1 : (value != 0);
+#endif
     } else if (strcmp(name, "carry_chunks") == 0) {
         o.carry_chunks = value > 0 ? static_cast<int>(value) : 0;
     } else if (strcmp(name, "no_wide_inv") == 0) {
@@ -587,7 +595,7 @@ static void sdry_runs(const PlanOptions& opt, int64_t rows, int64_t tiles, int n
 // Launches that move more than 1 GiB (four times the last-level cache) store their results with the streaming
 // hint; smaller ones leave them cacheable for the kernel that reads them next.  Plan option nt_stores overrides.
 static int streaming_stores(const PlanOptions& opt, int64_t b, int64_t n, int levels) {
-    if (opt.nt_stores >= 0) return opt.nt_stores != 0;
+    if (opt.nt_stores >= 0) return opt.nt_stores;
     return static_cast<double>(b) * static_cast<double>(n) * 8.0 * (levels + 2) > 1073741824.0;
 }
 

@@ -47,36 +47,33 @@ constexpr int wv_slot_w(int J, int j) { return kWvBuf * (1 + ((J - j + 1) & 3));
 
 // The four LDS-DMA instructions of one band chunk: samples [t0, t0 + 512) of `band_row` into the slot at LDS byte
 // address `ldst`, in the layout of the level that reads it (`voff`: the lane's swizzled byte offset inside a 1 KiB block).
-template <bool NT = false>
+// (HINT: 0 default cache policy, 1 streaming; the tuning build also knows the other combinations of the three policy bits)
+#define VW_WV_ISSUE_ASM(POLICY)                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                          \
+                 "global_load_lds_dwordx4 %1, %2" POLICY "\n\t"                                  \
+                 "global_load_lds_dwordx4 %1, %2 offset:1024" POLICY "\n\t"                      \
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" POLICY "\n\t"                      \
+                 "global_load_lds_dwordx4 %1, %2 offset:3072" POLICY "\n\t"                      \
+                 "s_mov_b32 m0, %0"                                                              \
+                 : "=&s"(keep)                                                                   \
+                 : "v"(voff), "s"(tsrc), "s"(ldst)                                               \
+                 : "memory")
+template <int HINT = 0>
 __device__ __forceinline__ void wv_issue(const double* __restrict__ band_row, int64_t t0, unsigned voff, unsigned ldst) {
     const double* tsrc = band_row + t0;  // wave-uniform
-    if (NT) {  // the same loads with the streaming hint
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2 nt\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
-            "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(tsrc), "s"(ldst)
-            : "memory");
-        return;
-    }
     // the instruction's immediate offset is added to the global address AND to the LDS address: one M0, one address
     // register and one offset register serve the four 1 KiB blocks
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(tsrc), "s"(ldst)
-        : "memory");
+    if (HINT == 1) VW_WV_ISSUE_ASM(" nt");
+#ifdef VW_TUNING
+    else if (HINT == 2) VW_WV_ISSUE_ASM(" sc1");
+    else if (HINT == 3) VW_WV_ISSUE_ASM(" sc0 sc1");
+    else if (HINT == 4) VW_WV_ISSUE_ASM(" sc1 nt");
+    else if (HINT == 5) VW_WV_ISSUE_ASM(" sc0 sc1 nt");
+    else if (HINT == 6) VW_WV_ISSUE_ASM(" sc0");
+    else if (HINT == 7) VW_WV_ISSUE_ASM(" sc0 nt");
+#endif
+    else VW_WV_ISSUE_ASM("");
 }
 
 // 16-byte store to a wave-uniform base plus a 32-bit byte offset per lane.  Written out so that the address stays an SGPR
@@ -91,6 +88,24 @@ __device__ __forceinline__ void wv_store16(double* sbase, unsigned voff, double2
     vw_f64x2 x;
     x.x = v.x;
     x.y = v.y;
+#ifdef VW_TUNING
+    if (nt == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        return;
+    }
+    if (nt == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        return;
+    }
+    if (nt == 4) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        return;
+    }
+    if (nt == 5) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
+        return;
+    }
+#endif
     if (nt)
         asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(voff), "v"(x), "s"(sbase) : "memory");
     else
@@ -381,7 +396,7 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
     const int nsteps = ndry + nreal;
     const bool nomath = VW_ABLATED(a, 0);
     const bool noload = VW_ABLATED(a, 1);
-    const bool nt_load = a.hoff[0] != 0;  // bands are read once: load them with the streaming hint
+    const int nt_load = a.hoff[0];  // bands are read once: load them with the streaming hint
 
     double tl[LT], th[LT];
 #pragma unroll
@@ -430,10 +445,24 @@ __global__ void __launch_bounds__(64, 2) k_inv_wave6(const InvArgs a) {
         if (noload) return;
         if (t0 + kWvSamples > n)
             wv_issue_edge<MODE>(band_row, t0, n, S, lane, lds_base + slot);
-        else if (nt_load)
-            wv_issue<true>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 1)
+            wv_issue<1>(band_row, t0, voff, lds_base + slot);
+#ifdef VW_TUNING
+        else if (nt_load == 2)
+            wv_issue<2>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 3)
+            wv_issue<3>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 4)
+            wv_issue<4>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 5)
+            wv_issue<5>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 6)
+            wv_issue<6>(band_row, t0, voff, lds_base + slot);
+        else if (nt_load == 7)
+            wv_issue<7>(band_row, t0, voff, lds_base + slot);
+#endif
         else
-            wv_issue(band_row, t0, voff, lds_base + slot);
+            wv_issue<0>(band_row, t0, voff, lds_base + slot);
     };
 
     // prologue: the first four bands of the first chunk
