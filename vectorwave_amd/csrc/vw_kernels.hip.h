@@ -133,6 +133,26 @@ __device__ __forceinline__ void gstore2(double* p, double2 v, int nt) {
         vw_f64x2 x;
         x.x = v.x;
         x.y = v.y;
+#ifdef VW_TUNING
+        // tuning build: the other cache-policy bits (plan option nt_stores = 2..5); the s_nop keeps a later VALU write of
+        // the data registers two wait states away from the store, which the compiler does not do for inline assembly
+        if (nt == 2) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+            return;
+        }
+        if (nt == 3) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+            return;
+        }
+        if (nt == 4) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+            return;
+        }
+        if (nt == 5) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+            return;
+        }
+#endif
         __builtin_nontemporal_store(x, reinterpret_cast<vw_f64x2*>(p));
     } else {
         *reinterpret_cast<double2*>(p) = v;
