@@ -1,7 +1,11 @@
 """Seeded random sweep over wavelet x length x depth x boundary x batch for the three C-ABI families
 (forward/inverse, SWT denoise, WaveletDenoiser): the HIP path against the oracle, bit for bit.  The fixed
 parity cases pin the shapes that matter; this sweep looks for the shapes nobody thought of (ragged lengths
-around tile and chunk edges, single rows, depth limits, filters longer than the signal)."""
+around tile and chunk edges, single rows, depth limits, filters longer than the signal).
+VW_FUZZ_SEED / VW_FUZZ_SCALE in the environment shift the seeds and multiply the case counts for a longer campaign (the
+test suite runs the default: 260 cases)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +16,9 @@ from vectorwave_amd.wavelets import get_wavelet
 from util import assert_bits_equal, gpu_denoise, gpu_forward, gpu_inverse
 
 pytestmark = pytest.mark.gpu
+
+SEED_SHIFT = int(os.environ.get("VW_FUZZ_SEED", "0"))
+SCALE = max(1, int(os.environ.get("VW_FUZZ_SCALE", "1")))
 
 WAVELETS = ["haar", "db2", "sym3", "db4", "db6", "db10", "sym4", "sym8", "sym11", "coif1", "coif3", "bior2.2", "bior4.4", "bior3.5", "rbio1.3", "db20"]
 EDGES = [1, 2, 3, 7, 8, 9, 31, 63, 64, 65, 255, 256, 257, 479, 480, 481, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049,
@@ -32,7 +39,7 @@ def _cases(seed, count):
     return out
 
 
-@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250101, 120))
+@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250101 + SEED_SHIFT, 120 * SCALE))
 def test_random_forward_inverse(ctx, wn, n, j, b, mode, seed):
     w = get_wavelet(wn)
     x = np.ascontiguousarray(np.random.default_rng(seed).standard_normal((b, n)))
@@ -51,7 +58,7 @@ def test_random_forward_inverse(ctx, wn, n, j, b, mode, seed):
     assert_bits_equal(gotx, o.reconstruct_batch(want, w, mode), "inverse %s N=%d J=%d mode=%d" % (wn, n, j, mode))
 
 
-@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250202, 60))
+@pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250202 + SEED_SHIFT, 60 * SCALE))
 def test_random_denoise(ctx, wn, n, j, b, mode, seed):
     w = get_wavelet(wn)
     if len(w.rec_hi) < len(w.rec_lo) and mode != 2:
@@ -96,7 +103,7 @@ def _stream_cases(seed, count):
     return out
 
 
-@pytest.mark.parametrize("wn,n,window,est,mult,method,mode,soft,seed", _stream_cases(20250303, 80))
+@pytest.mark.parametrize("wn,n,window,est,mult,method,mode,soft,seed", _stream_cases(20250303 + SEED_SHIFT, 80 * SCALE))
 def test_random_streaming_denoiser(ctx, wn, n, window, est, mult, method, mode, soft, seed):
     from vectorwave_amd import (BoundaryMode, MODWTStreamingDenoiser, NoiseEstimation, ThresholdMethod, ThresholdType)
     w = get_wavelet(wn)
