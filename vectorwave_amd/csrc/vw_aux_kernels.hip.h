@@ -29,6 +29,10 @@ struct LevelArgs {
     int32_t llo, lhi;   // taps used of lo / hi (after the reference's truncation)
     int32_t variant;    // inverse SYMMETRIC flavour, see k_level_inv
     int32_t use_in, use_din;  // 0 = treat the operand as all zeros
+    // inverse only: W_j is thresholded as it is read (apply_thr mode; 0 = none), threshold of row r at thr[r * thr_row_stride + thr_off]
+    int32_t thr_mode;
+    const double* thr;
+    int64_t thr_row_stride, thr_off;
     Taps taps;
 };
 
@@ -78,13 +82,19 @@ __global__ void __launch_bounds__(kThreads) k_level_inv(const LevelArgs a) {
     const double* __restrict__ ap = a.in + row * a.in_stride;
     const double* __restrict__ dp = a.din + row * a.din_stride;
     const int64_t n = a.n;
+    const bool shrink = a.thr_mode != 0 && a.use_din;
+    const double thr = shrink ? a.thr[row * a.thr_row_stride + a.thr_off] : 0.0;
     double sum = 0.0;
     if (MODE == kSymmetric && a.variant == 0) {
         const int lmax = a.llo > a.lhi ? a.llo : a.lhi;
         for (int l = 0; l < lmax; ++l) {
             const int64_t idx = sym_reflect(t - static_cast<int64_t>(l) * a.stride, n);
             if (l < a.llo) sum = sum + a.taps.lo[l] * (a.use_in ? ap[idx] : 0.0);
-            if (l < a.lhi) sum = sum + a.taps.hi[l] * (a.use_din ? dp[idx] : 0.0);
+            if (l < a.lhi) {
+                double dv = a.use_din ? dp[idx] : 0.0;
+                if (shrink) dv = apply_thr(dv, thr, a.thr_mode);
+                sum = sum + a.taps.hi[l] * dv;
+            }
         }
     } else {
         for (int l = 0; l < a.llo; ++l) {
@@ -102,7 +112,8 @@ __global__ void __launch_bounds__(kThreads) k_level_inv(const LevelArgs a) {
             }
             if (ok) {
                 const double av = a.use_in ? ap[idx] : 0.0;
-                const double dv = a.use_din ? dp[idx] : 0.0;
+                double dv = a.use_din ? dp[idx] : 0.0;
+                if (shrink) dv = apply_thr(dv, thr, a.thr_mode);
                 sum = sum + (a.taps.lo[l] * av + a.taps.hi[l] * dv);
             }
         }

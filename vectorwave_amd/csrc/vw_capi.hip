@@ -1262,6 +1262,12 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
             a.variant = single ? ((flags & VW_FLAG_SYMMETRIC_BATCH_VARIANT) ? 2 : 1) : 0;
             a.use_in = use_rin ? 1 : 0;
             a.use_din = ((band_mask >> (j - 1)) & 1u) ? 1 : 0;
+            // a level whose context fits no tile kernel inside a thresholding plan (e.g. 22 taps at level 9): W_j is
+            // thresholded as this kernel reads it, like the tile kernels on either side do
+            a.thr_mode = thr_mode;
+            a.thr = thr_rows;
+            a.thr_row_stride = thr_row_stride;
+            a.thr_off = static_cast<int64_t>(j - 1) * thr_level_stride;
             a.taps = taps;
             const int64_t per_row = (n + kThreads - 1) / kThreads;
             const int64_t nblocks = per_row * b;
