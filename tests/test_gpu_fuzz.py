@@ -2,8 +2,10 @@
 (forward/inverse, SWT denoise, WaveletDenoiser): the HIP path against the oracle, bit for bit.  The fixed
 parity cases pin the shapes that matter; this sweep looks for the shapes nobody thought of (ragged lengths
 around tile and chunk edges, single rows, depth limits, filters longer than the signal).
-VW_FUZZ_SEED / VW_FUZZ_SCALE in the environment shift the seeds and multiply the case counts for a longer campaign (the
-test suite runs the default: 260 cases)."""
+VW_FUZZ_SEED / VW_FUZZ_SCALE in the environment shift the seeds and multiply the case counts for a longer campaign,
+VW_FUZZ_NMAX / VW_FUZZ_BMAX raise the longest random row (default 9000) and the largest batch (default 4); cases whose
+oracle would take too long (dense filters of deep levels on long rows) are redrawn with fewer levels.  The test suite
+runs the default: 260 cases."""
 import os
 
 import numpy as np
@@ -19,6 +21,9 @@ pytestmark = pytest.mark.gpu
 
 SEED_SHIFT = int(os.environ.get("VW_FUZZ_SEED", "0"))
 SCALE = max(1, int(os.environ.get("VW_FUZZ_SCALE", "1")))
+NMAX = max(2, int(os.environ.get("VW_FUZZ_NMAX", "9000")))
+BMAX = max(1, int(os.environ.get("VW_FUZZ_BMAX", "4")))
+ORACLE_BUDGET = 1.5e9  # multiply-adds of the reference's dense inverse per case
 
 WAVELETS = ["haar", "db2", "sym3", "db4", "db6", "db10", "sym4", "sym8", "sym11", "coif1", "coif3", "bior2.2", "bior4.4", "bior3.5", "rbio1.3", "db20"]
 EDGES = [1, 2, 3, 7, 8, 9, 31, 63, 64, 65, 255, 256, 257, 479, 480, 481, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049,
@@ -30,11 +35,14 @@ def _cases(seed, count):
     out = []
     for _ in range(count):
         wn = WAVELETS[rng.integers(len(WAVELETS))]
-        n = int(EDGES[rng.integers(len(EDGES))] if rng.random() < 0.6 else rng.integers(1, 9000))
+        n = int(EDGES[rng.integers(len(EDGES))] if rng.random() < 0.6 else rng.integers(1, NMAX))
         mode = int(rng.integers(3))
-        b = int(rng.integers(1, 5))
-        jmax = o.max_levels(n, len(get_wavelet(wn).dec_lo))
+        b = int(rng.integers(1, BMAX + 1))
+        taps = len(get_wavelet(wn).dec_lo)
+        jmax = o.max_levels(n, taps)
         j = int(rng.integers(1, max(jmax, 1) + 1))
+        while (NMAX > 9000 or BMAX > 4) and j > 1 and float(n) * b * taps * (1 << j) > ORACLE_BUDGET:
+            j -= 1
         out.append((wn, n, j, b, mode, int(rng.integers(1 << 30))))
     return out
 
