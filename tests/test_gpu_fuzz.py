@@ -24,6 +24,25 @@ SCALE = max(1, int(os.environ.get("VW_FUZZ_SCALE", "1")))
 NMAX = max(2, int(os.environ.get("VW_FUZZ_NMAX", "9000")))
 BMAX = max(1, int(os.environ.get("VW_FUZZ_BMAX", "4")))
 ORACLE_BUDGET = 1.5e9  # multiply-adds of the reference's dense inverse per case
+# VW_FUZZ_PLANS=1: every case also draws one or two plan options (vw_set_plan_option: equivalent launch plans, same bits)
+PLANS = os.environ.get("VW_FUZZ_PLANS", "0") != "0"
+PLAN_CHOICES = [("no_sym_tiles", [1]), ("no_ring", [1]), ("no_blk", [1]), ("no_sdry", [1]), ("no_row_denoise", [1]), ("no_band_regs", [1]),
+                ("no_reg_select", [1]), ("no_wg_select", [1]), ("no_vec2", [1]), ("no_unroll", [1]), ("stream_wgs", [1, 6, 24]),
+                ("fwd_chunks", [1, 2, 3, 5, 16]), ("sdry_chunks", [1, 3, 1000]), ("carry_chunks", [2, 3, 8]),
+                ("inv_wave", [1, 2, 3, 5, 1000]), ("no_wide_inv", [1]), ("nt_stores", [0, 1])]
+
+
+def _draw_plan(plan, seed):
+    if not PLANS:
+        return ""
+    rng = np.random.default_rng(seed ^ 0x5eed)
+    picked = []
+    for _ in range(int(rng.integers(1, 3))):
+        name, values = PLAN_CHOICES[rng.integers(len(PLAN_CHOICES))]
+        value = values[rng.integers(len(values))]
+        plan(name, value)
+        picked.append("%s=%d" % (name, value))
+    return " [" + ",".join(picked) + "]"
 
 WAVELETS = ["haar", "db2", "sym3", "db4", "db6", "db10", "sym4", "sym8", "sym11", "coif1", "coif3", "bior2.2", "bior4.4", "bior3.5", "rbio1.3", "db20"]
 EDGES = [1, 2, 3, 7, 8, 9, 31, 63, 64, 65, 255, 256, 257, 479, 480, 481, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049,
@@ -48,8 +67,9 @@ def _cases(seed, count):
 
 
 @pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250101 + SEED_SHIFT, 120 * SCALE))
-def test_random_forward_inverse(ctx, wn, n, j, b, mode, seed):
+def test_random_forward_inverse(ctx, plan, wn, n, j, b, mode, seed):
     w = get_wavelet(wn)
+    opts = _draw_plan(plan, seed)
     x = np.ascontiguousarray(np.random.default_rng(seed).standard_normal((b, n)))
     st, want = o.decompose_batch(x, w, j, mode)
     gst, got, _ = gpu_forward(ctx, x, wn, j, mode)
@@ -57,20 +77,21 @@ def test_random_forward_inverse(ctx, wn, n, j, b, mode, seed):
         assert gst == N.VW_E_LEVEL  # beyond the reference's level limit
         return
     assert gst == 0, ctx.last_error()
-    assert_bits_equal(got, want, "forward %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    assert_bits_equal(got, want, "forward %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
     gst, gotx, _ = gpu_inverse(ctx, want, wn, mode)
     if len(w.rec_hi) < len(w.rec_lo) and mode != 2:
         assert gst == N.VW_E_LENGTH_MISMATCH  # the reference indexes out of bounds here
         return
     assert gst == 0, ctx.last_error()
-    assert_bits_equal(gotx, o.reconstruct_batch(want, w, mode), "inverse %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    assert_bits_equal(gotx, o.reconstruct_batch(want, w, mode), "inverse %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
 
 
 @pytest.mark.parametrize("wn,n,j,b,mode,seed", _cases(20250202 + SEED_SHIFT, 60 * SCALE))
-def test_random_denoise(ctx, wn, n, j, b, mode, seed):
+def test_random_denoise(ctx, plan, wn, n, j, b, mode, seed):
     w = get_wavelet(wn)
     if len(w.rec_hi) < len(w.rec_lo) and mode != 2:
         pytest.skip("the reference cannot invert this wavelet")
+    opts = _draw_plan(plan, seed)
     rng = np.random.default_rng(seed)
     x = np.ascontiguousarray(np.sin(np.arange(n) / 5.0)[None] + 0.3 * rng.standard_normal((b, n)))
     soft = bool(seed & 1)
@@ -81,7 +102,7 @@ def test_random_denoise(ctx, wn, n, j, b, mode, seed):
         assert gst == N.VW_E_LEVEL
         return
     assert gst == 0, ctx.last_error()
-    assert_bits_equal(got, want, "swt denoise %s N=%d J=%d mode=%d" % (wn, n, j, mode))
+    assert_bits_equal(got, want, "swt denoise %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
     method = [o.UNIVERSAL, o.MINIMAX, o.BAYES][seed % 3]
     if n > (2000 if NMAX <= 9000 else NMAX):
         return
