@@ -29,7 +29,8 @@ PLANS = os.environ.get("VW_FUZZ_PLANS", "0") != "0"
 PLAN_CHOICES = [("no_sym_tiles", [1]), ("no_ring", [1]), ("no_blk", [1]), ("no_sdry", [1]), ("no_row_denoise", [1]), ("no_band_regs", [1]),
                 ("no_reg_select", [1]), ("no_wg_select", [1]), ("no_vec2", [1]), ("no_unroll", [1]), ("stream_wgs", [1, 6, 24]),
                 ("fwd_chunks", [1, 2, 3, 5, 16]), ("sdry_chunks", [1, 3, 1000]), ("carry_chunks", [2, 3, 8]),
-                ("inv_wave", [1, 2, 3, 5, 1000]), ("no_wide_inv", [1]), ("nt_stores", [0, 1])]
+                ("inv_wave", [1, 2, 3, 5, 1000]), ("no_wide_inv", [1]), ("nt_stores", [0, 1]), ("no_soa_runs", [1]),
+                ("soa_run_len", [8, 16, 32])]
 
 
 def _draw_plan(plan, seed):
@@ -158,6 +159,44 @@ def test_random_band_masks_and_finite_checks(ctx, wn, n, j, b, mode, seed):
     cb.reshape(-1)[at[1]] = np.nan
     gst, _, bad = gpu_inverse(ctx, cb, wn, mode, N.VW_FLAG_CHECK_FINITE)
     assert gst == N.VW_E_NONFINITE and bad == at[0], (gst, bad, at)
+
+
+def _single_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        wn = WAVELETS[rng.integers(len(WAVELETS))]
+        n = int(EDGES[rng.integers(len(EDGES))] if rng.random() < 0.5 else rng.integers(1, NMAX))
+        out.append((wn, n, int(rng.integers(1, 4 * BMAX + 1)), int(rng.integers(3)), int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("wn,n,b,mode,seed", _single_cases(20250505 + SEED_SHIFT, 80 * SCALE))
+def test_random_single_level_and_soa(ctx, plan, wn, n, b, mode, seed):
+    """MODWTTransform.forward / inverse / inverseBatchOptimized (modwt/MODWTTransform.java:193-287, 600-660) and
+    BatchSIMDMODWT.batchMODWTSoA (modwt/BatchSIMDMODWT.java:64-274) on random shapes."""
+    w = get_wavelet(wn)
+    opts = _draw_plan(plan, seed)
+    x = np.ascontiguousarray(np.random.default_rng(seed).standard_normal((b, n)))
+    want = o.modwt_forward_batch(x, w, mode)
+    st, got, _ = gpu_forward(ctx, x, wn, 1, mode, N.VW_FLAG_SINGLE_LEVEL)
+    assert st == 0, ctx.last_error()
+    assert_bits_equal(got, want, "single forward %s N=%d b=%d mode=%d%s" % (wn, n, b, mode, opts))
+    if len(w.rec_hi) >= len(w.rec_lo):
+        for variant, flag in ((0, 0), (1, N.VW_FLAG_SYMMETRIC_BATCH_VARIANT)):
+            wantx = o.modwt_inverse_batch(want, w, mode, batch_variant=variant)
+            st, gotx, _ = gpu_inverse(ctx, want, wn, mode, N.VW_FLAG_SINGLE_LEVEL | flag)
+            assert st == 0, ctx.last_error()
+            assert_bits_equal(gotx, wantx, "single inverse variant %d %s N=%d b=%d mode=%d%s" % (variant, wn, n, b, mode, opts))
+    taps = len(w.dec_lo)
+    if len(w.dec_hi) == taps and n >= taps - 1:  # (the reference's index (t - l + N) % N goes negative below that)
+        from vectorwave_amd import BatchSIMDMODWT
+        soa = o.convert_to_soa(x)
+        a, d = np.empty(b * n), np.empty(b * n)
+        BatchSIMDMODWT.batchMODWTSoA(soa, a, d, w, b, n, ctx)
+        wa, wd = o.batch_modwt_soa(soa, w, b, n)
+        assert_bits_equal(a, wa, "soaApprox %s %d x %d" % (wn, b, n))
+        assert_bits_equal(d, wd, "soaDetail %s %d x %d" % (wn, b, n))
 
 
 def _stream_cases(seed, count):
