@@ -108,6 +108,43 @@ def dev_inverse(ctx, c_t, wname, boundary, flags=0, out=None):
     return out
 
 
+def bind_dev_forward(ctx, x_t, wname, levels, boundary, flags, out):
+    """dev_forward with the argument marshalling done once: returns a zero-argument callable (for timing loops in which
+    the per-call cost of building ctypes arguments would otherwise dominate a launch-bound configuration)."""
+    import torch
+    w = get_wavelet(wname)
+    h, g = _t(w.dec_lo), _t(w.dec_hi)
+    b, n = x_t.shape
+    sp = C.c_void_p(torch.cuda.current_stream(x_t.device).cuda_stream)
+    fn = ctx.lib.vw_modwt_forward_batch_dev
+    args = (ctx.handle, C.c_void_p(x_t.data_ptr()), C.c_int64(b), C.c_int64(n), C.c_int32(levels), _dp(h), C.c_int32(h.size), _dp(g),
+            C.c_int32(g.size), C.c_int32(boundary), C.c_uint32(flags), C.c_void_p(out.data_ptr()), None, sp)
+    keep = (h, g)
+
+    def call():
+        st = fn(*args)
+        assert st == 0 and keep is not None, ctx.last_error()
+    return call
+
+
+def bind_dev_inverse(ctx, c_t, wname, boundary, flags, out):
+    """dev_inverse with the argument marshalling done once (see bind_dev_forward)."""
+    import torch
+    w = get_wavelet(wname)
+    hr, gr = _t(w.rec_lo), _t(w.rec_hi)
+    b, jp1, n = c_t.shape
+    sp = C.c_void_p(torch.cuda.current_stream(c_t.device).cuda_stream)
+    fn = ctx.lib.vw_modwt_inverse_batch_dev
+    args = (ctx.handle, C.c_void_p(c_t.data_ptr()), C.c_int64(b), C.c_int64(n), C.c_int32(jp1 - 1), _dp(hr), C.c_int32(hr.size), _dp(gr),
+            C.c_int32(gr.size), C.c_int32(boundary), C.c_uint32(flags), C.c_void_p(out.data_ptr()), None, sp)
+    keep = (hr, gr)
+
+    def call():
+        st = fn(*args)
+        assert st == 0 and keep is not None, ctx.last_error()
+    return call
+
+
 def dev_denoise(ctx, x_t, wname, levels, boundary, threshold, soft, out=None):
     import torch
     w = get_wavelet(wname)

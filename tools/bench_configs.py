@@ -29,7 +29,7 @@ def main():
     args = ap.parse_args()
     import torch
     from vectorwave_amd import _native as N
-    from util import dev_denoise, dev_forward, dev_inverse, dev_signals, dev_wavelet_denoise
+    from util import bind_dev_forward, bind_dev_inverse, dev_denoise, dev_signals, dev_wavelet_denoise
     from vectorwave_amd.wavelets import get_wavelet
 
     ctx = N.Context(0)
@@ -69,8 +69,9 @@ def main():
         x = dev_signals(rows, n, seed=1)
         c = torch.empty((rows, j + 1, n), dtype=torch.float64, device=x.device)
         xr = torch.empty_like(x)
-        f_ms = timed(lambda: dev_forward(ctx, x, wn, j, mode, flags, out=c))
-        i_ms = timed(lambda: dev_inverse(ctx, c, wn, mode, flags, out=xr))
+        # (arguments marshalled once: at 32 x 1000 the Python side of a call otherwise costs more than the launch)
+        f_ms = timed(bind_dev_forward(ctx, x, wn, j, mode, flags, c))
+        i_ms = timed(bind_dev_inverse(ctx, c, wn, mode, flags, xr))
         samples = rows * n
         bytes_dir = 8.0 * (j + 2) * samples
         w_ = get_wavelet(wn)
