@@ -26,6 +26,8 @@ BMAX = max(1, int(os.environ.get("VW_FUZZ_BMAX", "4")))
 ORACLE_BUDGET = 1.5e9  # multiply-adds of the reference's dense inverse per case
 # VW_FUZZ_PLANS=1: every case also draws one or two plan options (vw_set_plan_option: equivalent launch plans, same bits)
 PLANS = os.environ.get("VW_FUZZ_PLANS", "0") != "0"
+# VW_FUZZ_DEVICE=1: the denoise cases also go through the device-pointer entry point and the allocation-free one
+DEVICE = os.environ.get("VW_FUZZ_DEVICE", "0") != "0"
 PLAN_CHOICES = [("no_sym_tiles", [1]), ("no_ring", [1]), ("no_blk", [1]), ("no_sdry", [1]), ("no_row_denoise", [1]), ("no_band_regs", [1]),
                 ("no_reg_select", [1]), ("no_wg_select", [1]), ("no_vec2", [1]), ("no_unroll", [1]), ("stream_wgs", [1, 6, 24]),
                 ("fwd_chunks", [1, 2, 3, 5, 16]), ("sdry_chunks", [1, 3, 1000]), ("carry_chunks", [2, 3, 8]),
@@ -104,6 +106,16 @@ def test_random_denoise(ctx, plan, wn, n, j, b, mode, seed):
         return
     assert gst == 0, ctx.last_error()
     assert_bits_equal(got, want, "swt denoise %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
+    if DEVICE:
+        import torch
+        from test_zz_no_alloc import noalloc_denoise
+        from util import dev_denoise
+        x_t = torch.from_numpy(x).cuda()
+        dgot, _ = dev_denoise(ctx, x_t, wn, j, mode, thr, soft)
+        assert_bits_equal(dgot.cpu().numpy(), want, "device entry point %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
+        nst, ngot, _ = noalloc_denoise(ctx, x_t, wn, j, mode, thr, soft)
+        assert nst == 0, ctx.last_error()
+        assert_bits_equal(ngot.cpu().numpy(), want, "allocation-free entry point %s N=%d J=%d mode=%d%s" % (wn, n, j, mode, opts))
     method = [o.UNIVERSAL, o.MINIMAX, o.BAYES][seed % 3]
     if n > (2000 if NMAX <= 9000 else NMAX):
         return
