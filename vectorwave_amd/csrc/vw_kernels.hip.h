@@ -2185,19 +2185,38 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
     for (int i = 2 * tid; i < 2 * a.hist_cap; i += 2 * NT) *reinterpret_cast<double2*>(hstR + i) = make_double2(0.0, 0.0);
     lds_barrier();
 
-    // tile loader for any position: wraps (PERIODIC) or zero-fills (ZERO_PADDING) right of the row
-    auto load_tile = [&](const double* __restrict__ src, bool use, int64_t t0, double2(&v)[PPT]) {
+    // Tile loader for any position.  The loads must stay in flight across a whole level (that is their point), so nothing
+    // may touch the loaded registers until the band is published one level later: every lane loads from an address inside
+    // the row -- wrapped (PERIODIC) or clamped (ZERO_PADDING) -- and zeros for samples right of a ZERO_PADDING row or for
+    // a band that the mask switches off are put in by `settle` when the band is published.  (With the zero fill at load
+    // time the compiler merged the loaded value with the constant right behind the load and waited for it there: the
+    // memory latency of every level lay open, and the kernel took its memory time plus its arithmetic time.)
+    auto load_tile = [&](const double* __restrict__ src, int64_t t0, double2(&v)[PPT]) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            int64_t ia = t0 + k * CH + 2 * tid, ib = ia + 1;
+            if (MODE == kPeriodic) {
+                if (ia >= n) ia = (ia < 2 * n) ? ia - n : ia % n;
+                if (ib >= n) ib = (ib < 2 * n) ? ib - n : ib % n;
+            } else {
+                if (ia >= n) ia = (VEC2 == 1) ? n - 2 : n - 1;
+                if (ib >= n) ib = n - 1;
+            }
+            if (VEC2 == 1) {  // even n, aligned rows: a pair never straddles the row end
+                v[k] = *reinterpret_cast<const double2*>(src + ia);
+            } else {
+                v[k].x = src[ia];
+                v[k].y = src[ib];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // issued here, not where the scheduler finds room for them
+    };
+    auto settle = [&](bool use, int64_t t0, double2(&v)[PPT]) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int64_t t = t0 + k * CH + 2 * tid;
-            double2 x = make_double2(0.0, 0.0);
-            if (use) {
-                if (t + 1 < n || MODE != kPeriodic)
-                    x = gload_pair<VEC2>(src, t, n);
-                else
-                    x = gload_pair_wrapped<VEC2>(src, t, n);
-            }
-            v[k] = x;
+            if (!use || (MODE != kPeriodic && t >= n)) v[k].x = 0.0;
+            if (!use || (MODE != kPeriodic && t + 1 >= n)) v[k].y = 0.0;
         }
     };
     // the lanes that own the first hlen[j] samples of the tile swap them with the stored history, which
@@ -2230,9 +2249,10 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
         const int64_t t0 = static_cast<int64_t>(tile0 + ntl - 1 - ch) * T;
         const bool dry = ch < 0;
         if (ch == -ndry) {
-            load_tile(rrow, use_r, t0, preR);
-            load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, (a.band_mask >> (a.lev1 - 1)) & 1u, t0, pre);
+            load_tile(rrow, t0, preR);
+            load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, t0, pre);
         }
+        settle(use_r, t0, preR);
         if (a.first_bad != nullptr && a.check_rin && !dry) {
             const int64_t flat0 = row * a.w_row_stride + static_cast<int64_t>(a.lev1) * a.w_band_stride;
 #pragma unroll
@@ -2252,6 +2272,7 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
             const int s = 1 << (j - 1);
             const double thr = (a.thr_mode != 0) ? uniform_load_f64(a.thr + row * a.thr_row_stride + (j - 1) * a.thr_level_stride) : 0.0;
             // ---- publish W_j (thresholded on the way in when denoising) ---------------
+            settle(((a.band_mask >> (j - 1)) & 1u) != 0, t0, pre);
 #pragma unroll
             for (int c = 0; c < PPT; ++c) {
                 double2 w = pre[c];
@@ -2274,12 +2295,16 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
             lds_barrier();  // R_j and W_j visible
 
             // ---- loads that fly while this level is computed --------------------------
-            if (j > a.lev0) {
-                load_tile(wbase + static_cast<int64_t>(j - 2) * a.w_band_stride, (a.band_mask >> (j - 2)) & 1u, t0, pre);
-            } else if (ch + 1 < ntl) {
-                load_tile(rrow, use_r, t0 - T, preR);
-                load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, (a.band_mask >> (a.lev1 - 1)) & 1u,
-                          t0 - T, pre);
+            // the next detail band of this tile, or at the last level the first band of the next tile (and its R).  ONE
+            // load site for the band, taken on every path: two sites, or a site inside a branch, meet in a register
+            // copy right behind the load, and the copy waits for the data.  (Nothing is left to fetch at the last level of
+            // the last tile: it loads its own band again, unused.)
+            {
+                const bool nxt = (j == a.lev0), more = (ch + 1 < ntl);
+                const int jb = nxt ? a.lev1 - 1 : j - 2;
+                const int64_t tl = (nxt && more) ? t0 - T : t0;
+                load_tile(wbase + static_cast<int64_t>(jb) * a.w_band_stride, tl, pre);
+                if (nxt && more) load_tile(rrow, tl, preR);
             }
 
             double acc[PPT][2];
