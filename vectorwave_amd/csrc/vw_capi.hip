@@ -1086,6 +1086,7 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
 #ifdef VW_TUNING
             if (strstr(ctx->opt.ablate, "nostore")) a.n_store = 0;
             if (strstr(ctx->opt.ablate, "nocompute")) a.lh = 0;
+            if (strstr(ctx->opt.ablate, "noload")) a.ablate |= 2;
 #endif
             const bool vec2 = (n % 2 == 0) && (rin_stride % 2 == 0) && aligned16(rin) && aligned16(coeffs) && aligned16(rout);
             const int64_t nblocks = b * a.ntiles;

@@ -2202,6 +2202,10 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
                 if (ia >= n) ia = (VEC2 == 1) ? n - 2 : n - 1;
                 if (ib >= n) ib = n - 1;
             }
+            if (VW_ABLATED(a, 1)) {  // (tuning build: every lane reads the start of the row -- the same loads, no memory time)
+                ia = 0;
+                ib = 1 < n ? 1 : 0;
+            }
             if (VEC2 == 1) {  // even n, aligned rows: a pair never straddles the row end
                 v[k] = *reinterpret_cast<const double2*>(src + ia);
             } else {
