@@ -999,7 +999,8 @@ static int inverse_dev(vw_ctx* ctx, const double* coeffs, int64_t b, int64_t n, 
                 j = st.lev0 - 1;
                 continue;
             }
-            if (!generic_all && inv_halo(1, j, lhr) + 2 > kChunk) {
+            // (k_inv_sdry keeps 32-bit byte offsets into a row: rows below 2^29 samples)
+            if (!generic_all && inv_halo(1, j, lhr) + 2 > kChunk && n < (static_cast<int64_t>(1) << 29)) {
                 for (int lo = 1; lo <= j && st.sdry == 0; ++lo) {
                     st.sdry = plan_sdry(ctx, lo, j, lhr, true, st.hoff, st.hlen, &st.ndry, &st.hist_cap);
                     if (st.sdry != 0) st.lev0 = lo;

@@ -2191,7 +2191,10 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
     // a band that the mask switches off are put in by `settle` when the band is published.  (With the zero fill at load
     // time the compiler merged the loaded value with the constant right behind the load and waited for it there: the
     // memory latency of every level lay open, and the kernel took its memory time plus its arithmetic time.)
-    auto load_tile = [&](const double* __restrict__ src, int64_t t0, double2(&v)[PPT]) {
+    // (the byte offsets of a lane's samples inside a row depend on the tile alone: they are worked out once per tile, not
+    // once per level -- with sixteen waves in lock-step every instruction of the level loop costs the CU sixteen issue slots)
+    unsigned boa[PPT], bob[PPT];
+    auto tile_offsets = [&](int64_t t0) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             int64_t ia = t0 + k * CH + 2 * tid, ib = ia + 1;
@@ -2206,11 +2209,19 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
                 ia = 0;
                 ib = 1 < n ? 1 : 0;
             }
+            boa[k] = static_cast<unsigned>(ia) * 8u;  // rows of less than 2^29 samples (the planner checks)
+            bob[k] = static_cast<unsigned>(ib) * 8u;
+        }
+    };
+    auto load_tile = [&](const double* __restrict__ src, double2(&v)[PPT]) {
+        const char* __restrict__ base = reinterpret_cast<const char*>(src);  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
             if (VEC2 == 1) {  // even n, aligned rows: a pair never straddles the row end
-                v[k] = *reinterpret_cast<const double2*>(src + ia);
+                v[k] = *reinterpret_cast<const double2*>(base + boa[k]);
             } else {
-                v[k].x = src[ia];
-                v[k].y = src[ib];
+                v[k].x = *reinterpret_cast<const double*>(base + boa[k]);
+                v[k].y = *reinterpret_cast<const double*>(base + bob[k]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // issued here, not where the scheduler finds room for them
@@ -2253,8 +2264,9 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
         const int64_t t0 = static_cast<int64_t>(tile0 + ntl - 1 - ch) * T;
         const bool dry = ch < 0;
         if (ch == -ndry) {
-            load_tile(rrow, t0, preR);
-            load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, t0, pre);
+            tile_offsets(t0);
+            load_tile(rrow, preR);
+            load_tile(wbase + static_cast<int64_t>(a.lev1 - 1) * a.w_band_stride, pre);
         }
         settle(use_r, t0, preR);
         if (a.first_bad != nullptr && a.check_rin && !dry) {
@@ -2306,9 +2318,9 @@ __global__ void __launch_bounds__(NT) k_inv_sdry(const InvArgs a) {
             {
                 const bool nxt = (j == a.lev0), more = (ch + 1 < ntl);
                 const int jb = nxt ? a.lev1 - 1 : j - 2;
-                const int64_t tl = (nxt && more) ? t0 - T : t0;
-                load_tile(wbase + static_cast<int64_t>(jb) * a.w_band_stride, tl, pre);
-                if (nxt && more) load_tile(rrow, tl, preR);
+                if (nxt && more) tile_offsets(t0 - T);
+                load_tile(wbase + static_cast<int64_t>(jb) * a.w_band_stride, pre);
+                if (nxt && more) load_tile(rrow, preR);
             }
 
             double acc[PPT][2];
