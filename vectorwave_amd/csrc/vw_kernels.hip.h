@@ -835,18 +835,39 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
     for (int i = 2 * tid; i < a.hist_cap; i += 2 * NT) *reinterpret_cast<double2*>(hst + i) = make_double2(0.0, 0.0);
     lds_barrier();
 
-    // tile loader for any position: wraps (PERIODIC) or zero-fills (ZERO_PADDING) left of the row,
-    // zero-fills right of it
+    // Tile loader for any position.  The loads are to stay in flight while the tile before is computed, so nothing may
+    // touch the loaded registers until the tile is staged: every lane loads from an address inside the row -- wrapped
+    // (PERIODIC) or clamped -- and `settle` puts in the zeros (left of a ZERO_PADDING row, right of any row) when the tile
+    // is staged.  (A zero fill at load time, or a load site inside a branch, meets the loaded value in a register copy
+    // right behind the load, and the copy waits for the data.)
     auto load_tile = [&](int64_t t0, double2(&v)[PPT]) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
+            int64_t ia = t0 + k * CH + 2 * tid, ib = ia + 1;
+            if (MODE == kPeriodic) {
+                if (ia < 0) ia = (ia >= -n) ? ia + n : mod_wrap(ia, n);
+                if (ib < 0) ib = (ib >= -n) ? ib + n : mod_wrap(ib, n);
+            } else {
+                if (ia < 0) ia = 0;
+                if (ib < 0) ib = 0;
+            }
+            if (ia >= n) ia = (VEC2 == 1) ? n - 2 : n - 1;  // right of the row: zeros in every mode (settle)
+            if (ib >= n) ib = n - 1;
+            if (VEC2 == 1) {  // even n, aligned rows: a pair never straddles a row end
+                v[k] = *reinterpret_cast<const double2*>(inrow + ia);
+            } else {
+                v[k].x = inrow[ia];
+                v[k].y = inrow[ib];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // issued here, not where the scheduler finds room for them
+    };
+    auto settle = [&](int64_t t0, double2(&v)[PPT]) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
             const int64_t t = t0 + k * CH + 2 * tid;
-            double2 x = make_double2(0.0, 0.0);
-            if (t >= 0)
-                x = gload_pair<VEC2>(inrow, t, n);
-            else if (MODE == kPeriodic)
-                x = gload_pair_wrapped<VEC2>(inrow, t, n);
-            v[k] = x;
+            if (t >= n || (MODE != kPeriodic && t < 0)) v[k].x = 0.0;
+            if (t + 1 >= n || (MODE != kPeriodic && t + 1 < 0)) v[k].y = 0.0;
         }
     };
     // the lanes that own the last hlen[j] samples of the tile swap them with the stored history, which
@@ -871,6 +892,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
         const int64_t t0 = static_cast<int64_t>(tile0 + ch) * T;
         const bool dry = ch < 0;
         if (ch == -ndry) load_tile(t0, pre);
+        settle(t0, pre);
         if (a.first_bad != nullptr && !dry) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -885,7 +907,7 @@ __global__ void __launch_bounds__(NT) k_fwd_sdry(const FwdArgs a) {
         for (int k = 0; k < PPT; ++k) *reinterpret_cast<double2*>(buf + HALO + k * CH + 2 * tid) = pre[k];
         hist_swap(a.lev0, pre);
         lds_barrier();
-        if (ch + 1 < ntl) load_tile(t0 + T, pre);  // in flight while this tile is computed
+        load_tile(ch + 1 < ntl ? t0 + T : t0, pre);  // in flight while this tile is computed (after the last tile: itself, unused)
 
         for (int j = a.lev0; j <= a.lev1; ++j) {
             const int s = 1 << (j - 1);
