@@ -1422,7 +1422,7 @@ __device__ __forceinline__ void inv_blk_level1(const char* lds, int tid, const d
 }
 
 template <int LT, int MODE, bool VEC2, bool FMA>
-__global__ void __launch_bounds__(kThreads, 4) k_inv_blk(const InvArgs a) {
+__global__ void __launch_bounds__(kThreads, 3) k_inv_blk(const InvArgs a) {
     extern __shared__ double2 vw_smem[];
     constexpr int PPT = 4, NP = 5;
     constexpr int T = PPT * kChunk;
