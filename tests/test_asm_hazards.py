@@ -77,3 +77,16 @@ def test_wave_kernel_unit_has_no_inline_asm_hazard(tmp_path):
     text = out.read_text()
     assert "global_store_dwordx4" in text and ";;#ASMSTART" in text
     assert H.scan(str(out)) == 0
+    # k_inv_wave6 counts its vector-memory operations by hand (s_waitcnt vmcnt(N) with N worked out from the LDS-DMA and
+    # store instructions it issues): a register spilled to scratch would add loads and stores of the compiler's own to
+    # that counter and make every count wrong.  No instantiation may use scratch.
+    import re
+    kernels = 0
+    for block in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        if "k_inv_wave6" not in name:
+            continue
+        kernels += 1
+        assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1)) == 0, name
+        assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1)) == 0, name
+    assert kernels >= 12, kernels
